@@ -1,0 +1,99 @@
+"""Seeded synthetic sparse-vector workloads (the reference ships no generator).
+
+Per vector: `nnz` distinct dims from the term distribution (uniform, or Zipf p_t ~ 1/rank^s with term ids
+randomly permuted), values |N(0,1)| + 0.05, L2-normalised in double the way the reference's client does
+(benchmark/LoadGenerator.scala:34-37).  Random sparse vectors almost never reach cosine 0.8, so a fraction
+`dup_frac` of the rows is replaced by a perturbed copy of an earlier base row (10 % of the terms replaced,
+values scaled by U(0.9, 1.1), re-normalised) which gives a non-empty, checkable result set.
+"""
+import numpy as np
+
+# BASELINE.json configs -> (N, dim, nnz, zipf_s, theta); seed = 20240 + config index
+CONFIGS = {
+    "c2": dict(n=100_000, dim=10_000, nnz=50, zipf_s=1.0, theta=0.5, seed=20241),
+    "c3": dict(n=1_000_000, dim=100_000, nnz=100, zipf_s=0.0, theta=0.8, seed=20242),
+    "c3z": dict(n=1_000_000, dim=100_000, nnz=100, zipf_s=0.5, theta=0.8, seed=20242),
+    "c5": dict(n=10_000_000, dim=1_000_000, nnz=200, zipf_s=0.0, theta=0.9, seed=20244),
+}
+
+
+def _draw_terms_uniform(rng, rows, dim, nnz):
+    # sorted draw from [0, dim - nnz] plus 0..nnz-1 is strictly increasing and < dim
+    a = rng.integers(0, dim - nnz + 1, size=(rows, nnz), dtype=np.int64)
+    a.sort(axis=1)
+    a += np.arange(nnz, dtype=np.int64)[None, :]
+    return a.astype(np.int32)
+
+
+def _draw_terms_zipf(rng, rows, dim, nnz, cdf, perm):
+    out = np.empty((rows, nnz), np.int32)
+    over = 3
+    for r0 in range(0, rows, 4096):
+        r1 = min(rows, r0 + 4096)
+        m = r1 - r0
+        draws = np.searchsorted(cdf, rng.random((m, nnz * over)), side="right").astype(np.int64)
+        np.minimum(draws, dim - 1, out=draws)
+        for i in range(m):
+            u, first = np.unique(draws[i], return_index=True)
+            u = u[np.argsort(first)][:nnz]
+            if u.size < nnz:  # top up with unused terms
+                extra = np.setdiff1d(rng.permutation(dim)[: 4 * nnz], u)[: nnz - u.size]
+                u = np.concatenate([u, extra])
+            out[r0 + i] = np.sort(perm[u])
+    return out
+
+
+def make_vectors(n, dim, nnz, zipf_s=0.0, seed=0, dup_frac=0.05):
+    """Returns CSR (rowptr int64[n+1], indices int32[n*nnz], values float64[n*nnz]); rows have exactly
+    `nnz` strictly increasing indices and unit L2 norm."""
+    assert 0 < nnz <= dim
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if zipf_s > 0:
+        p = 1.0 / np.arange(1, dim + 1, dtype=np.float64) ** zipf_s
+        cdf = np.cumsum(p / p.sum())
+        perm = rng.permutation(dim).astype(np.int64)
+        idx = _draw_terms_zipf(rng, n, dim, nnz, cdf, perm)
+    else:
+        idx = _draw_terms_uniform(rng, n, dim, nnz)
+    val = np.abs(rng.standard_normal((n, nnz))) + 0.05
+
+    # planted near-duplicates (sources are BASE rows, so no chains)
+    if dup_frac > 0 and n > 1:
+        is_dup = rng.random(n) < dup_frac
+        is_dup[0] = False
+        rows = np.nonzero(is_dup)[0]
+        src = (rng.random(rows.size) * rows).astype(np.int64)  # uniform in [0, row)
+        base_idx = idx[src].copy()
+        base_val = val[src] * rng.uniform(0.9, 1.1, size=(rows.size, nnz))
+        n_rep = max(1, nnz // 10)
+        for j in range(rows.size):
+            pos = rng.choice(nnz, size=n_rep, replace=False)
+            new_terms = rng.integers(0, dim, size=n_rep)
+            row = base_idx[j]
+            for p_, t_ in zip(pos, new_terms):
+                if t_ not in row:
+                    row[p_] = t_
+            order = np.argsort(row, kind="stable")
+            base_idx[j] = row[order]
+            base_val[j] = base_val[j][order]
+        idx[rows] = base_idx
+        val[rows] = base_val
+
+    val /= np.sqrt((val * val).sum(axis=1, keepdims=True))
+    rowptr = np.arange(0, (n + 1) * nnz, nnz, dtype=np.int64)
+    return rowptr, idx.reshape(-1).astype(np.int32), val.reshape(-1).astype(np.float64)
+
+
+def make_config(name, n=None):
+    """One of BASELINE.json's synthetic configs (optionally truncated to the first n rows' worth)."""
+    c = dict(CONFIGS[name])
+    if n is not None:
+        c["n"] = n
+    rowptr, idx, val = make_vectors(c["n"], c["dim"], c["nnz"], c["zipf_s"], c["seed"])
+    return c, rowptr, idx, val
+
+
+def workload_counts(dim, rowptr, indices):
+    """Analytic work of a full self-join: (postings, posting visits = sum_t df_t^2)."""
+    df = np.bincount(indices, minlength=dim).astype(np.float64)
+    return int(indices.size), float((df * df).sum())
