@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI in include/apss.h (libapss_hip.so).  No fallback: a missing library raises."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+SO_PATH = os.path.join(CSRC, "libapss_hip.so")
+
+OK, E_INVALID, E_NOMEM, E_DEVICE, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+FLAG_VALUE_PRUNE, FLAG_ADMISSION, FLAG_NORMALIZE, FLAG_FORCE_SCAN = 1, 2, 4, 8
+
+# every symbol include/apss.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "apss_create", "apss_destroy", "apss_last_error", "apss_set_stream", "apss_insert", "apss_query",
+    "apss_insert_and_query", "apss_self_join", "apss_result_count", "apss_fetch_results", "apss_size",
+    "apss_stats_get", "apss_insert_dev", "apss_query_dev", "apss_insert_and_query_dev", "apss_clear",
+    "apss_results_dev", "apss_partial_scores_dev",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("dim", C.c_int32), ("theta", C.c_double),
+                ("index_threshold", C.c_double), ("flags", C.c_uint32), ("device_id", C.c_int32),
+                ("term_lo", C.c_int32), ("term_hi", C.c_int32), ("tile_rows", C.c_int32),
+                ("reserved0", C.c_int32), ("capacity_rows", C.c_int64), ("capacity_nnz", C.c_int64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("tiles", C.c_int64), ("posting_visits", C.c_int64),
+                ("candidate_pairs", C.c_int64), ("result_pairs", C.c_int64), ("probe_ms", C.c_double),
+                ("build_ms", C.c_double), ("probe_launches", C.c_int64), ("hbm_bytes", C.c_int64)]
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  In-tree output, travels with gpurun."""
+    srcs = [os.path.join(CSRC, f) for f in ("apss_hip.hip", "apss_kernels.hpp")] + [
+        os.path.normpath(os.path.join(CSRC, "..", "..", "include", "apss.h"))]
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(s) for s in srcs):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-o", SO_PATH,
+                           os.path.join(CSRC, "apss_hip.hip")])
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Loads libapss_hip.so; raises if it has not been built (there is no CPU path to fall back to)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("libapss_hip.so is not built (%s): run __graft_entry__.build() / make -C %s. "
+                           "There is no CPU fallback." % (SO_PATH, CSRC))
+    L = C.CDLL(SO_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    pi64 = C.POINTER(C.c_int64)
+    L.apss_create.restype = i32
+    L.apss_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.apss_destroy.restype = None
+    L.apss_destroy.argtypes = [vp]
+    L.apss_last_error.restype = C.c_char_p
+    L.apss_last_error.argtypes = [vp]
+    L.apss_set_stream.restype = i32
+    L.apss_set_stream.argtypes = [vp, vp]
+    for name in ("apss_insert",):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, i64, vp, vp, vp, vp]
+    for name in ("apss_query", "apss_insert_and_query"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, i64, vp, vp, vp, vp, pi64]
+    L.apss_self_join.restype = i32
+    L.apss_self_join.argtypes = [vp, pi64]
+    L.apss_result_count.restype = i32
+    L.apss_result_count.argtypes = [vp, pi64]
+    L.apss_fetch_results.restype = i32
+    L.apss_fetch_results.argtypes = [vp, i64, i64, vp, vp, vp]
+    L.apss_size.restype = i32
+    L.apss_size.argtypes = [vp, pi64, pi64]
+    L.apss_stats_get.restype = i32
+    L.apss_stats_get.argtypes = [vp, C.POINTER(Stats)]
+    L.apss_insert_dev.restype = i32
+    L.apss_insert_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    for name in ("apss_query_dev", "apss_insert_and_query_dev"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, i64, i64, vp, vp, vp, vp, pi64]
+    L.apss_clear.restype = i32
+    L.apss_clear.argtypes = [vp]
+    L.apss_results_dev.restype = i32
+    L.apss_results_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), pi64]
+    L.apss_partial_scores_dev.restype = i32
+    L.apss_partial_scores_dev.argtypes = [vp, i64, vp, vp, vp]
+    _lib = L
+    return L

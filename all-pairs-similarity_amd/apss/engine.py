@@ -1,0 +1,168 @@
+"""Python face of one device-resident index (one IndexingWorkerActor's state on one MI355X).
+
+Mirrors the seam the C ABI replaces -- `case IndexData(vectors)` of
+core/src/main/scala/cpslab/deploy/server/IndexingWorkerActor.scala:123-137 -- and nothing else.  All compute
+is in libapss_hip.so; errors surface as ApssError carrying the library's message."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class ApssError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("apss error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
+
+
+class ApssIndex:
+    def __init__(self, dim, theta, device=0, tile_rows=0, term_range=None, flags=0, index_threshold=0.0,
+                 capacity_rows=0, capacity_nnz=0):
+        L = _lib.lib()
+        cfg = _lib.Config()
+        cfg.struct_size = C.sizeof(_lib.Config)
+        cfg.dim = int(dim)
+        cfg.theta = float(theta)
+        cfg.index_threshold = float(index_threshold)
+        cfg.flags = int(flags)
+        cfg.device_id = int(device)
+        cfg.term_lo, cfg.term_hi = (0, 0) if term_range is None else (int(term_range[0]), int(term_range[1]))
+        cfg.tile_rows = int(tile_rows)
+        cfg.capacity_rows = int(capacity_rows)
+        cfg.capacity_nnz = int(capacity_nnz)
+        h = C.c_void_p()
+        rc = L.apss_create(C.byref(cfg), C.byref(h))
+        if rc != _lib.OK:
+            raise ApssError(rc, (L.apss_last_error(None) or b"").decode())
+        self._h = h
+        self._L = L
+        self.dim, self.theta = int(dim), float(theta)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.apss_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != _lib.OK:
+            raise ApssError(rc, (self._L.apss_last_error(self._h) or b"").decode())
+
+    # -- host-pointer path (numpy in / numpy out)
+    def _csr(self, ids, rowptr, indices, values):
+        ids, rowptr = _np(ids, np.int64), _np(rowptr, np.int64)
+        indices, values = _np(indices, np.int32), _np(values, np.float64)
+        if rowptr.size != ids.size + 1:
+            raise ValueError("rowptr must have len(ids) + 1 entries")
+        return ids, rowptr, indices, values
+
+    def insert(self, ids, rowptr, indices, values):
+        """buildInvertedIndex(batch), IWA:61-71"""
+        ids, rowptr, indices, values = self._csr(ids, rowptr, indices, values)
+        self._chk(self._L.apss_insert(self._h, ids.size, _ptr(rowptr), _ptr(indices), _ptr(values), _ptr(ids)))
+
+    def query(self, ids, rowptr, indices, values):
+        """querySimilarItems(batch) on the frozen index (IWA:74-111 with stopUpdateIndex)"""
+        ids, rowptr, indices, values = self._csr(ids, rowptr, indices, values)
+        n = C.c_int64(0)
+        self._chk(self._L.apss_query(self._h, ids.size, _ptr(rowptr), _ptr(indices), _ptr(values), _ptr(ids), C.byref(n)))
+        return self.fetch()
+
+    def insert_and_query(self, ids, rowptr, indices, values):
+        """the IndexData handler, IWA:123-137"""
+        ids, rowptr, indices, values = self._csr(ids, rowptr, indices, values)
+        n = C.c_int64(0)
+        self._chk(self._L.apss_insert_and_query(self._h, ids.size, _ptr(rowptr), _ptr(indices), _ptr(values), _ptr(ids),
+                                                C.byref(n)))
+        return self.fetch()
+
+    def self_join(self, fetch=True):
+        n = C.c_int64(0)
+        self._chk(self._L.apss_self_join(self._h, C.byref(n)))
+        return self.fetch() if fetch else n.value
+
+    def result_count(self):
+        n = C.c_int64(0)
+        self._chk(self._L.apss_result_count(self._h, C.byref(n)))
+        return n.value
+
+    def fetch(self):
+        """(query ext ids, candidate ext ids, scores) of the last query-type call"""
+        n = self.result_count()
+        q, c, s = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.float32)
+        if n:
+            self._chk(self._L.apss_fetch_results(self._h, 0, n, _ptr(q), _ptr(c), _ptr(s)))
+        return q, c, s
+
+    def size(self):
+        r, z = C.c_int64(0), C.c_int64(0)
+        self._chk(self._L.apss_size(self._h, C.byref(r), C.byref(z)))
+        return r.value, z.value
+
+    def stats(self):
+        st = _lib.Stats()
+        self._chk(self._L.apss_stats_get(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _lib.Stats._fields_}
+
+    def clear(self):
+        self._chk(self._L.apss_clear(self._h))
+
+    # -- device-pointer path (torch tensors on this handle's GPU; torch is plumbing only)
+    def set_stream(self, cuda_stream_handle):
+        self._chk(self._L.apss_set_stream(self._h, C.c_void_p(cuda_stream_handle)))
+
+    @staticmethod
+    def _dev(rowptr, indices, values, ids):
+        import torch
+        assert rowptr.dtype == torch.int64 and indices.dtype == torch.int32
+        assert values.dtype == torch.float32 and ids.dtype == torch.int64
+        for t in (rowptr, indices, values, ids):
+            assert t.is_cuda and t.is_contiguous()
+        return (ids.numel(), indices.numel(), C.c_void_p(rowptr.data_ptr()), C.c_void_p(indices.data_ptr()),
+                C.c_void_p(values.data_ptr()), C.c_void_p(ids.data_ptr()))
+
+    def insert_dev(self, ids, rowptr, indices, values):
+        n, nnz, rp, ix, vl, ex = self._dev(rowptr, indices, values, ids)
+        self._chk(self._L.apss_insert_dev(self._h, n, nnz, rp, ix, vl, ex))
+
+    def query_dev(self, ids, rowptr, indices, values):
+        n, nnz, rp, ix, vl, ex = self._dev(rowptr, indices, values, ids)
+        out = C.c_int64(0)
+        self._chk(self._L.apss_query_dev(self._h, n, nnz, rp, ix, vl, ex, C.byref(out)))
+        return out.value
+
+    def insert_and_query_dev(self, ids, rowptr, indices, values):
+        n, nnz, rp, ix, vl, ex = self._dev(rowptr, indices, values, ids)
+        out = C.c_int64(0)
+        self._chk(self._L.apss_insert_and_query_dev(self._h, n, nnz, rp, ix, vl, ex, C.byref(out)))
+        return out.value
+
+    def results_dev(self):
+        """raw device pointers (q_row int32*, c_slot int32*, score float*, n) of the last results"""
+        a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        self._chk(self._L.apss_results_dev(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return a.value, b.value, c.value, n.value
+
+    def partial_scores_dev(self, q_row, c_slot, out):
+        import torch
+        assert q_row.dtype == torch.int32 and c_slot.dtype == torch.int32 and out.dtype == torch.float32
+        self._chk(self._L.apss_partial_scores_dev(self._h, q_row.numel(), C.c_void_p(q_row.data_ptr()),
+                                                  C.c_void_p(c_slot.data_ptr()), C.c_void_p(out.data_ptr())))

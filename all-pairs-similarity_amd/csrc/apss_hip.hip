@@ -1,0 +1,713 @@
+// apss_hip.hip -- C ABI (include/apss.h) over the HIP kernels of apss_kernels.hpp.
+//
+// One handle == one IndexingWorkerActor's state (vectorsStore + invertedIndex + similarityThreshold,
+// IndexingWorkerActor.scala:21-25) resident in the HBM of one MI355X.  No CPU compute path exists here: every
+// entry point either runs the HIP kernels or fails with APSS_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/apss.h"
+#include "apss_kernels.hpp"
+
+using namespace apss;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;  // elements
+};
+
+}  // namespace
+
+struct apss_handle {
+  apss_config cfg{};
+  int dev = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  bool sharded = false;
+  bool nonneg = true;  // every stored / queried weight so far is >= 0
+  int32_t cb = 32768;
+
+  // store (CSR) -- vectorsStore, IWA:22
+  int64_t n_rows = 0, nnz = 0;
+  DevBuf<int64_t> rowptr, ext;
+  DevBuf<int32_t> idx;
+  DevBuf<float> val, sub;  // sub: shard sub-norm per row (sharded only)
+  // index (tile-major CSC) -- invertedIndex, IWA:25
+  int64_t n_tiles = 0;
+  DevBuf<uint32_t> tile_ptr;
+  DevBuf<Posting> post;
+  DevBuf<float> tile_min;
+  // query staging (apss_query: batch not stored)
+  DevBuf<int64_t> q_rowptr, q_ext;
+  DevBuf<int32_t> q_idx;
+  DevBuf<float> q_val, q_sub;
+  // ingest scratch
+  DevBuf<int64_t> s_keep, s_cnt, s_rowdst, s_nnzdst, in_rowptr, in_ext;
+  DevBuf<int32_t> in_idx;
+  DevBuf<float> s_inv, s_sub, in_val;
+  // results of the last query-type call
+  DevBuf<int32_t> res_q, res_c;
+  DevBuf<float> res_s;
+  int64_t n_res = -1;
+  const int64_t *res_q_ext = nullptr;      // ext ids of the last query batch (device)
+  const int64_t *last_q_rowptr = nullptr;  // last query batch CSR (device), for apss_partial_scores_dev
+  const int32_t *last_q_idx = nullptr;
+  const float *last_q_val = nullptr;
+  int64_t last_nq = 0;
+  DevBuf<unsigned long long> counters;
+  DevBuf<unsigned int> flagword;
+  // stats
+  apss_stats st{};
+  size_t bytes_reserved = 0;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                  \
+      return e_ == hipErrorOutOfMemory ? APSS_E_NOMEM : APSS_E_DEVICE;                               \
+    }                                                                                                \
+  } while (0)
+
+#define APSS_TRY(expr)          \
+  do {                          \
+    int32_t rc_ = (expr);       \
+    if (rc_ != APSS_OK) return rc_; \
+  } while (0)
+
+int32_t fail(apss_handle *h, int32_t rc, const std::string &msg) {
+  h->err = msg;
+  return rc;
+}
+
+// grow-only device array; keeps the first `keep` elements
+template <class T>
+int32_t ensure(apss_handle *h, DevBuf<T> &b, size_t n, size_t keep = 0, bool exact = false) {
+  if (n <= b.cap && b.p) return APSS_OK;
+  size_t ncap = exact ? n : std::max(n, b.cap + b.cap / 2);
+  ncap = std::max<size_t>(ncap, 64);
+  T *np = nullptr;
+  HIPCHK(h, hipMalloc((void **)&np, ncap * sizeof(T)));
+  if (keep && b.p) HIPCHK(h, hipMemcpyAsync(np, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+  if (b.p) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(b.p));
+    h->bytes_reserved -= b.cap * sizeof(T);
+  }
+  b.p = np;
+  b.cap = ncap;
+  h->bytes_reserved += ncap * sizeof(T);
+  return APSS_OK;
+}
+
+template <class T>
+void release(DevBuf<T> &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+int32_t enter(apss_handle *h) {
+  if (!h) return APSS_E_INVALID;
+  hipError_t e = hipSetDevice(h->dev);
+  if (e != hipSuccess) return fail(h, APSS_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  return APSS_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- ingest: validate (+ optional normalise / admission / value prune / term-range filter) and append ----
+// Source arrays are device pointers (batch-relative rowptr).  Destination: the store (to_store) or the query
+// staging buffers.  *n_out / *nnz_out: rows / entries that survived.
+int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_idx,
+               const float *d_val, const int64_t *d_ext, bool to_store, int64_t *n_out, int64_t *nnz_out) {
+  *n_out = 0;
+  *nnz_out = 0;
+  if (n == 0) return APSS_OK;
+  const bool transform = h->sharded || (h->cfg.flags & (APSS_FLAG_VALUE_PRUNE | APSS_FLAG_ADMISSION | APSS_FLAG_NORMALIZE));
+  APSS_TRY(ensure(h, h->s_keep, (size_t)n + 1));
+  APSS_TRY(ensure(h, h->s_cnt, (size_t)n + 1));
+  APSS_TRY(ensure(h, h->s_inv, (size_t)n));
+  APSS_TRY(ensure(h, h->s_sub, (size_t)n));
+  APSS_TRY(ensure(h, h->flagword, 4));
+  HIPCHK(h, hipMemsetAsync(h->flagword.p, 0, 4 * sizeof(unsigned int), h->stream));
+
+  IngestArgs a{};
+  a.n = n;
+  a.rowptr = d_rowptr;
+  a.idx = d_idx;
+  a.val = d_val;
+  a.dim = h->cfg.dim;
+  a.term_lo = h->cfg.term_lo;
+  a.term_hi = h->cfg.term_hi;
+  a.flags = h->cfg.flags;
+  a.theta = (float)h->cfg.theta;
+  a.index_threshold = (float)h->cfg.index_threshold;
+  a.row_keep = h->s_keep.p;
+  a.row_cnt = h->s_cnt.p;
+  a.row_inv = h->s_inv.p;
+  a.row_sub = h->s_sub.p;
+  a.flags_out = h->flagword.p;
+  const int threads = 256;
+  const int64_t blocks = ceil_div(n * kGroup, threads);
+  hipLaunchKernelGGL(k_ingest_count, dim3((unsigned)blocks), dim3(threads), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+
+  // destination
+  int64_t dst_row0 = to_store ? h->n_rows : 0, dst_nnz0 = to_store ? h->nnz : 0;
+  int64_t kept_rows = n, kept_nnz = nnz;
+  unsigned int flags_host = 0;
+  if (transform) {
+    APSS_TRY(ensure(h, h->s_rowdst, (size_t)n + 1));
+    APSS_TRY(ensure(h, h->s_nnzdst, (size_t)n + 1));
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->s_keep.p, h->s_rowdst.p, n);
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->s_cnt.p, h->s_nnzdst.p, n);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(&kept_rows, h->s_rowdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&kept_nnz, h->s_nnzdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipMemcpyAsync(&flags_host, h->flagword.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (flags_host & 1u)
+    return fail(h, APSS_E_INVALID, "malformed vector: indices must be strictly increasing and in [0, dim) "
+                                   "(SparseVector.scala:75; vectorDim mismatch is the require of CommonUtils.scala:99)");
+  if (flags_host & 2u) return fail(h, APSS_E_INVALID, "non-finite value in a vector");
+  if (flags_host & 4u) h->nonneg = false;
+
+  DevBuf<int64_t> &o_rowptr = to_store ? h->rowptr : h->q_rowptr;
+  DevBuf<int64_t> &o_ext = to_store ? h->ext : h->q_ext;
+  DevBuf<int32_t> &o_idx = to_store ? h->idx : h->q_idx;
+  DevBuf<float> &o_val = to_store ? h->val : h->q_val;
+  DevBuf<float> &o_sub = to_store ? h->sub : h->q_sub;
+  APSS_TRY(ensure(h, o_rowptr, (size_t)(dst_row0 + kept_rows + 1), (size_t)(to_store ? dst_row0 + 1 : 0)));
+  APSS_TRY(ensure(h, o_ext, (size_t)(dst_row0 + kept_rows), (size_t)dst_row0));
+  APSS_TRY(ensure(h, o_idx, (size_t)(dst_nnz0 + kept_nnz), (size_t)dst_nnz0));
+  APSS_TRY(ensure(h, o_val, (size_t)(dst_nnz0 + kept_nnz), (size_t)dst_nnz0));
+  if (h->sharded) APSS_TRY(ensure(h, o_sub, (size_t)(dst_row0 + kept_rows), (size_t)dst_row0));
+  if (dst_row0 == 0) HIPCHK(h, hipMemsetAsync(o_rowptr.p, 0, sizeof(int64_t), h->stream));
+
+  IngestWriteArgs w{};
+  w.in = a;
+  w.dst_row0 = dst_row0;
+  w.dst_nnz0 = dst_nnz0;
+  w.o_rowptr = o_rowptr.p;
+  w.o_idx = o_idx.p;
+  w.o_val = o_val.p;
+  w.o_ext = o_ext.p;
+  w.o_sub = h->sharded ? o_sub.p : nullptr;
+  w.ext = d_ext;
+  if (transform) {
+    w.row_dst = h->s_rowdst.p;
+    w.nnz_dst = h->s_nnzdst.p;
+  } else {
+    // identity placement: row r -> r, entry k -> k; reuse the batch rowptr as the entry scan and a ramp for rows
+    APSS_TRY(ensure(h, h->s_rowdst, (size_t)n + 1));
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->s_keep.p, h->s_rowdst.p, n);
+    HIPCHK(h, hipGetLastError());
+    w.row_dst = h->s_rowdst.p;
+    w.nnz_dst = d_rowptr;
+  }
+  hipLaunchKernelGGL(k_ingest_write, dim3((unsigned)blocks), dim3(threads), 0, h->stream, w);
+  HIPCHK(h, hipGetLastError());
+  *n_out = kept_rows;
+  *nnz_out = kept_nnz;
+  return APSS_OK;
+}
+
+// ---- index build for rows [row0, n_rows): rebuild every tile that contains one of them ----
+int32_t build_tiles(apss_handle *h, int64_t row0) {
+  const int64_t cb = h->cb;
+  const int64_t tile0 = row0 / cb;
+  const int64_t n_tiles = ceil_div(h->n_rows, cb);
+  const int64_t stride = (int64_t)h->cfg.dim + 2;
+  APSS_TRY(ensure(h, h->tile_ptr, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
+  if (h->post.cap < (size_t)std::max<int64_t>(h->nnz, 1)) return fail(h, APSS_E_STATE, "postings not reserved");
+  if (h->sharded) APSS_TRY(ensure(h, h->tile_min, (size_t)n_tiles, (size_t)tile0));
+  h->n_tiles = n_tiles;
+  if (n_tiles == tile0) return APSS_OK;
+  const int64_t r0 = tile0 * cb;
+  HIPCHK(h, hipMemsetAsync(h->tile_ptr.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint32_t), h->stream));
+  BuildArgs b{};
+  b.rowptr = h->rowptr.p;
+  b.idx = h->idx.p;
+  b.val = h->val.p;
+  b.row0 = r0;
+  b.row1 = h->n_rows;
+  b.cb = (int32_t)cb;
+  b.dim = h->cfg.dim;
+  b.tile_ptr = h->tile_ptr.p;
+  b.tp_stride = stride;
+  b.post = h->post.p;
+  const int threads = 256;
+  const int64_t blocks = ceil_div((h->n_rows - r0) * kWave, threads);
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
+  hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, h->tile_ptr.p, stride,
+                     h->cfg.dim, tile0);
+  hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
+  if (h->sharded)
+    hipLaunchKernelGGL(k_tile_min_sub, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream,
+                       (const float *)h->sub.p, h->n_rows, (int32_t)cb, h->tile_min.p, tile0);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->st.build_ms = ms;
+  return APSS_OK;
+}
+
+// the store's postings array must keep earlier tiles when it is reallocated: ensure() with keep
+int32_t reserve_postings(apss_handle *h, int64_t new_nnz, int64_t keep_nnz) {
+  return ensure(h, h->post, (size_t)std::max<int64_t>(new_nnz, 1), (size_t)keep_nnz);
+}
+
+template <int MODE>
+int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
+  auto kern = k_probe<MODE, kProbeBlock>;
+  HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(kProbeBlock), lds, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  return APSS_OK;
+}
+
+// ---- probe the whole index with a query batch resident on the device ----
+int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t *q_idx, const float *q_val,
+              const int64_t *q_ext, const float *q_sub, int64_t q_slot_base, int64_t *n_results) {
+  h->res_q_ext = q_ext;
+  h->last_q_rowptr = q_rowptr;
+  h->last_q_idx = q_idx;
+  h->last_q_val = q_val;
+  h->last_nq = nq;
+  h->n_res = 0;
+  h->st.posting_visits = h->st.candidate_pairs = h->st.result_pairs = 0;
+  h->st.probe_ms = 0;
+  h->st.probe_launches = 0;
+  if (n_results) *n_results = 0;
+  APSS_TRY(ensure(h, h->counters, kCtrCount));
+  if (nq == 0 || h->n_tiles == 0) return APSS_OK;
+  if (nq > 0x7fffffffLL) return fail(h, APSS_E_INVALID, "query batch too large");
+
+  const double theta = h->cfg.theta;
+  int mode;
+  if (!(theta > 0.0)) mode = 2;
+  else if (!h->nonneg || (h->cfg.flags & APSS_FLAG_FORCE_SCAN)) mode = 1;
+  else mode = 0;
+
+  ProbeArgs a{};
+  a.tile_ptr = h->tile_ptr.p;
+  a.tp_stride = (int64_t)h->cfg.dim + 2;
+  a.post = h->post.p;
+  a.store_rowptr = h->rowptr.p;
+  a.ext_id = h->ext.p;
+  a.c_scale = h->sharded ? h->sub.p : nullptr;
+  a.tile_scale = h->sharded ? h->tile_min.p : nullptr;
+  a.n_rows = h->n_rows;
+  a.cb = h->cb;
+  a.n_tiles = (int32_t)h->n_tiles;
+  a.q_rowptr = q_rowptr;
+  a.q_idx = q_idx;
+  a.q_val = q_val;
+  a.q_ext = q_ext;
+  a.q_scale = h->sharded ? q_sub : nullptr;
+  a.nq = (int32_t)nq;
+  // ~2 workgroups per CU per tile in flight at once, tiles swept one after another (tile-major grid) so the
+  // chip works on one tile's postings at a time and they stay in L2 / Infinity Cache
+  const int64_t want_chunks = 512;
+  a.q_chunk = (int32_t)std::max<int64_t>(1, ceil_div(nq, want_chunks));
+  a.n_chunks = (int32_t)ceil_div(nq, a.q_chunk);
+  a.q_slot_base = q_slot_base;
+  a.theta = (float)theta;
+  a.counters = h->counters.p;
+  const size_t lds = probe_lds_bytes(h->cb, kProbeBlock, mode);
+
+  if (h->res_q.cap == 0) {
+    const size_t cap0 = 1u << 20;
+    APSS_TRY(ensure(h, h->res_q, cap0, 0, true));
+    APSS_TRY(ensure(h, h->res_c, cap0, 0, true));
+    APSS_TRY(ensure(h, h->res_s, cap0, 0, true));
+  }
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    a.res_q = h->res_q.p;
+    a.res_c = h->res_c.p;
+    a.res_s = h->res_s.p;
+    a.res_cap = h->res_q.cap;
+    HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (mode == 0) APSS_TRY(launch_probe<0>(h, a, lds));
+    else if (mode == 1) APSS_TRY(launch_probe<1>(h, a, lds));
+    else APSS_TRY(launch_probe<2>(h, a, lds));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    unsigned long long c[kCtrCount];
+    HIPCHK(h, hipMemcpyAsync(c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->st.probe_ms += ms;
+    h->st.probe_launches++;
+    h->st.posting_visits = (int64_t)c[kCtrVisits];
+    h->st.candidate_pairs = (int64_t)c[kCtrCands];
+    h->st.result_pairs = (int64_t)c[kCtrResults];
+    if (c[kCtrResults] <= a.res_cap) {
+      h->n_res = (int64_t)c[kCtrResults];
+      if (n_results) *n_results = h->n_res;
+      return APSS_OK;
+    }
+    // the result list overflowed: grow to what the run asked for and repeat the (idempotent) probe
+    const size_t need = (size_t)c[kCtrResults] + (size_t)c[kCtrResults] / 8 + 1024;
+    APSS_TRY(ensure(h, h->res_q, need, 0, true));
+    APSS_TRY(ensure(h, h->res_c, need, 0, true));
+    APSS_TRY(ensure(h, h->res_s, need, 0, true));
+  }
+  return fail(h, APSS_E_STATE, "result buffer kept overflowing");
+}
+
+int32_t validate_host_csr(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices,
+                          const double *values, const int64_t *ext_ids) {
+  if (n < 0) return fail(h, APSS_E_INVALID, "negative row count");
+  if (n == 0) return APSS_OK;
+  if (!rowptr || !ext_ids) return fail(h, APSS_E_INVALID, "null rowptr / ext_ids");
+  if (rowptr[0] != 0) return fail(h, APSS_E_INVALID, "rowptr[0] must be 0");
+  for (int64_t i = 0; i < n; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(h, APSS_E_INVALID, "rowptr must be non-decreasing");
+  if (rowptr[n] > 0 && (!indices || !values)) return fail(h, APSS_E_INVALID, "null indices / values");
+  return APSS_OK;
+}
+
+// host CSR (double values) -> device input staging (float values)
+int32_t upload(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices, const double *values,
+               const int64_t *ext_ids) {
+  const int64_t nnz = n ? rowptr[n] : 0;
+  APSS_TRY(ensure(h, h->in_rowptr, (size_t)n + 1));
+  APSS_TRY(ensure(h, h->in_ext, (size_t)std::max<int64_t>(n, 1)));
+  APSS_TRY(ensure(h, h->in_idx, (size_t)std::max<int64_t>(nnz, 1)));
+  APSS_TRY(ensure(h, h->in_val, (size_t)std::max<int64_t>(nnz, 1)));
+  std::vector<float> f((size_t)nnz);
+  for (int64_t k = 0; k < nnz; ++k) f[(size_t)k] = (float)values[k];
+  if (n) {
+    HIPCHK(h, hipMemcpyAsync(h->in_rowptr.p, rowptr, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->in_ext.p, ext_ids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  }
+  if (nnz) {
+    HIPCHK(h, hipMemcpyAsync(h->in_idx.p, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->in_val.p, f.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // `f` goes out of scope
+  return APSS_OK;
+}
+
+int32_t insert_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_idx,
+                        const float *d_val, const int64_t *d_ext, int64_t *first_new_row) {
+  *first_new_row = h->n_rows;
+  if (n == 0) return APSS_OK;
+  if (h->n_rows + n > 0x7fffffffLL) return fail(h, APSS_E_INVALID, "more than 2^31 - 1 vectors in one handle");
+  // postings of the tiles that stay must survive growth of the array
+  const int64_t keep_rows = h->n_rows / h->cb * h->cb;
+  int64_t keep_nnz = 0;
+  if (keep_rows > 0 && h->post.cap < (size_t)(h->nnz + nnz)) {
+    HIPCHK(h, hipMemcpyAsync(&keep_nnz, h->rowptr.p + keep_rows, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  int64_t kept_rows = 0, kept_nnz = 0;
+  APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, true, &kept_rows, &kept_nnz));
+  const int64_t row0 = h->n_rows;
+  h->n_rows += kept_rows;
+  h->nnz += kept_nnz;
+  APSS_TRY(reserve_postings(h, h->nnz, keep_nnz));
+  APSS_TRY(build_tiles(h, row0));
+  return APSS_OK;
+}
+
+int32_t query_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_idx,
+                       const float *d_val, const int64_t *d_ext, int64_t *n_results) {
+  int64_t kept_rows = 0, kept_nnz = 0;
+  APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, false, &kept_rows, &kept_nnz));
+  return probe(h, kept_rows, h->q_rowptr.p, h->q_idx.p, h->q_val.p, h->q_ext.p, h->q_sub.p, -1, n_results);
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int32_t apss_create(const apss_config *cfg, apss_handle **out) {
+  if (!cfg || !out) {
+    g_create_error = "null argument";
+    return APSS_E_INVALID;
+  }
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(apss_config)) {
+    g_create_error = "apss_config.struct_size mismatch";
+    return APSS_E_INVALID;
+  }
+  if (cfg->dim <= 0 || !std::isfinite(cfg->theta)) {
+    g_create_error = "dim must be > 0 and theta finite";
+    return APSS_E_INVALID;
+  }
+  apss_handle *h = new (std::nothrow) apss_handle();
+  if (!h) return APSS_E_NOMEM;
+  h->cfg = *cfg;
+  if (h->cfg.term_hi == 0 && h->cfg.term_lo == 0) h->cfg.term_hi = cfg->dim;
+  if (h->cfg.term_lo < 0 || h->cfg.term_hi > cfg->dim || h->cfg.term_lo >= h->cfg.term_hi) {
+    g_create_error = "bad term range";
+    delete h;
+    return APSS_E_INVALID;
+  }
+  h->sharded = !(h->cfg.term_lo == 0 && h->cfg.term_hi == cfg->dim);
+  h->cb = cfg->tile_rows ? cfg->tile_rows : 32768;
+  if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {
+    g_create_error = "tile_rows must be a multiple of 64 in [64, 32768]";
+    delete h;
+    return APSS_E_INVALID;
+  }
+  if (h->sharded && !(cfg->theta > 0.0)) {
+    g_create_error = "term-range shards need theta > 0 (candidate test p_g >= theta*|q_g|*|c_g|)";
+    delete h;
+    return APSS_E_UNSUPPORTED;
+  }
+  h->dev = cfg->device_id;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || h->dev < 0 || h->dev >= ndev) {
+    g_create_error = std::string("no usable HIP device (there is no CPU fallback): ") +
+                     (e != hipSuccess ? hipGetErrorString(e) : "device ordinal out of range");
+    delete h;
+    return APSS_E_DEVICE;
+  }
+  if ((e = hipSetDevice(h->dev)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+    g_create_error = std::string("HIP init failed: ") + hipGetErrorString(e);
+    delete h;
+    return APSS_E_DEVICE;
+  }
+  h->stream = h->own_stream;
+  if (cfg->capacity_rows > 0) {
+    if (ensure(h, h->rowptr, (size_t)cfg->capacity_rows + 1, 0, true) != APSS_OK ||
+        ensure(h, h->ext, (size_t)cfg->capacity_rows, 0, true) != APSS_OK) {
+      g_create_error = h->err;
+      apss_destroy(h);
+      return APSS_E_NOMEM;
+    }
+  }
+  if (cfg->capacity_nnz > 0) {
+    if (ensure(h, h->idx, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
+        ensure(h, h->val, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
+        ensure(h, h->post, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK) {
+      g_create_error = h->err;
+      apss_destroy(h);
+      return APSS_E_NOMEM;
+    }
+  }
+  *out = h;
+  return APSS_OK;
+}
+
+void apss_destroy(apss_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->dev);
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  release(h->rowptr); release(h->ext); release(h->idx); release(h->val); release(h->sub);
+  release(h->tile_ptr); release(h->post); release(h->tile_min);
+  release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
+  release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
+  release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val);
+  release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+const char *apss_last_error(const apss_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int32_t apss_set_stream(apss_handle *h, void *hip_stream) {
+  APSS_TRY(enter(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return APSS_OK;
+}
+
+int32_t apss_insert(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices, const double *values,
+                    const int64_t *ext_ids) {
+  APSS_TRY(enter(h));
+  APSS_TRY(validate_host_csr(h, n, rowptr, indices, values, ext_ids));
+  if (n == 0) return APSS_OK;
+  APSS_TRY(upload(h, n, rowptr, indices, values, ext_ids));
+  int64_t first = 0;
+  return insert_dev_impl(h, n, rowptr[n], h->in_rowptr.p, h->in_idx.p, h->in_val.p, h->in_ext.p, &first);
+}
+
+int32_t apss_query(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices, const double *values,
+                   const int64_t *ext_ids, int64_t *n_results) {
+  APSS_TRY(enter(h));
+  APSS_TRY(validate_host_csr(h, n, rowptr, indices, values, ext_ids));
+  APSS_TRY(upload(h, n, rowptr, indices, values, ext_ids));
+  return query_dev_impl(h, n, n ? rowptr[n] : 0, h->in_rowptr.p, h->in_idx.p, h->in_val.p, h->in_ext.p, n_results);
+}
+
+int32_t apss_insert_and_query(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices,
+                              const double *values, const int64_t *ext_ids, int64_t *n_results) {
+  APSS_TRY(enter(h));
+  APSS_TRY(validate_host_csr(h, n, rowptr, indices, values, ext_ids));
+  APSS_TRY(upload(h, n, rowptr, indices, values, ext_ids));
+  return apss_insert_and_query_dev(h, n, n ? rowptr[n] : 0, h->in_rowptr.p, h->in_idx.p, h->in_val.p, h->in_ext.p,
+                                   n_results);
+}
+
+int32_t apss_self_join(apss_handle *h, int64_t *n_results) {
+  APSS_TRY(enter(h));
+  return probe(h, h->n_rows, h->rowptr.p, h->idx.p, h->val.p, h->ext.p, h->sub.p, 0, n_results);
+}
+
+int32_t apss_result_count(const apss_handle *h, int64_t *n_results) {
+  if (!h || !n_results) return APSS_E_INVALID;
+  if (h->n_res < 0) return APSS_E_STATE;
+  *n_results = h->n_res;
+  return APSS_OK;
+}
+
+__global__ void k_gather_ids(const int32_t *res_q, const int32_t *res_c, const int64_t *q_ext, const int64_t *c_ext,
+                             int64_t n, int64_t *out_q, int64_t *out_c) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    out_q[i] = q_ext[res_q[i]];
+    out_c[i] = c_ext[res_c[i]];
+  }
+}
+
+int32_t apss_fetch_results(apss_handle *h, int64_t offset, int64_t count, int64_t *out_q, int64_t *out_c,
+                           float *out_score) {
+  APSS_TRY(enter(h));
+  if (h->n_res < 0) return fail(h, APSS_E_STATE, "no query has run on this handle");
+  if (offset < 0 || count < 0 || offset + count > h->n_res) return fail(h, APSS_E_INVALID, "fetch range out of bounds");
+  if (count == 0) return APSS_OK;
+  if (!out_q || !out_c || !out_score) return fail(h, APSS_E_INVALID, "null output buffer");
+  // map (query row, candidate slot) to external ids on the device, then copy out
+  APSS_TRY(ensure(h, h->s_rowdst, (size_t)count));
+  APSS_TRY(ensure(h, h->s_nnzdst, (size_t)count));
+  hipLaunchKernelGGL(k_gather_ids, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, h->stream,
+                     (const int32_t *)h->res_q.p + offset, (const int32_t *)h->res_c.p + offset, h->res_q_ext,
+                     (const int64_t *)h->ext.p, count, h->s_rowdst.p, h->s_nnzdst.p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out_q, h->s_rowdst.p, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out_c, h->s_nnzdst.p, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out_score, h->res_s.p + offset, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return APSS_OK;
+}
+
+int32_t apss_size(const apss_handle *h, int64_t *rows, int64_t *nnz) {
+  if (!h) return APSS_E_INVALID;
+  if (rows) *rows = h->n_rows;
+  if (nnz) *nnz = h->nnz;
+  return APSS_OK;
+}
+
+int32_t apss_stats_get(apss_handle *h, apss_stats *out) {
+  if (!h || !out) return APSS_E_INVALID;
+  h->st.rows = h->n_rows;
+  h->st.nnz = h->nnz;
+  h->st.tiles = h->n_tiles;
+  h->st.hbm_bytes = (int64_t)h->bytes_reserved;
+  *out = h->st;
+  return APSS_OK;
+}
+
+int32_t apss_insert_dev(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_indices,
+                        const float *d_values, const int64_t *d_ext_ids) {
+  APSS_TRY(enter(h));
+  if (n < 0 || nnz < 0) return fail(h, APSS_E_INVALID, "negative size");
+  if (n > 0 && (!d_rowptr || !d_ext_ids || (nnz > 0 && (!d_indices || !d_values))))
+    return fail(h, APSS_E_INVALID, "null device pointer");
+  int64_t first = 0;
+  return insert_dev_impl(h, n, nnz, d_rowptr, d_indices, d_values, d_ext_ids, &first);
+}
+
+int32_t apss_query_dev(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_indices,
+                       const float *d_values, const int64_t *d_ext_ids, int64_t *n_results) {
+  APSS_TRY(enter(h));
+  if (n < 0 || nnz < 0) return fail(h, APSS_E_INVALID, "negative size");
+  if (n > 0 && (!d_rowptr || !d_ext_ids || (nnz > 0 && (!d_indices || !d_values))))
+    return fail(h, APSS_E_INVALID, "null device pointer");
+  return query_dev_impl(h, n, nnz, d_rowptr, d_indices, d_values, d_ext_ids, n_results);
+}
+
+int32_t apss_insert_and_query_dev(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr,
+                                  const int32_t *d_indices, const float *d_values, const int64_t *d_ext_ids,
+                                  int64_t *n_results) {
+  APSS_TRY(enter(h));
+  if (n < 0 || nnz < 0) return fail(h, APSS_E_INVALID, "negative size");
+  if (n > 0 && (!d_rowptr || !d_ext_ids || (nnz > 0 && (!d_indices || !d_values))))
+    return fail(h, APSS_E_INVALID, "null device pointer");
+  int64_t first = 0;
+  APSS_TRY(insert_dev_impl(h, n, nnz, d_rowptr, d_indices, d_values, d_ext_ids, &first));
+  const int64_t nq = h->n_rows - first;
+  // the batch is now rows [first, n_rows) of the store: query it in place (rowptr offsets are absolute)
+  return probe(h, nq, h->rowptr.p + first, h->idx.p, h->val.p, h->ext.p + first, h->sharded ? h->sub.p + first : nullptr,
+               first, n_results);
+}
+
+int32_t apss_clear(apss_handle *h) {
+  APSS_TRY(enter(h));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->n_rows = 0;
+  h->nnz = 0;
+  h->n_tiles = 0;
+  h->n_res = -1;
+  h->nonneg = true;
+  return APSS_OK;
+}
+
+int32_t apss_results_dev(apss_handle *h, const int32_t **d_q_row, const int32_t **d_c_slot, const float **d_score,
+                         int64_t *n_results) {
+  if (!h) return APSS_E_INVALID;
+  if (h->n_res < 0) return fail(h, APSS_E_STATE, "no query has run on this handle");
+  if (d_q_row) *d_q_row = h->res_q.p;
+  if (d_c_slot) *d_c_slot = h->res_c.p;
+  if (d_score) *d_score = h->res_s.p;
+  if (n_results) *n_results = h->n_res;
+  return APSS_OK;
+}
+
+int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *d_q_row, const int32_t *d_c_slot,
+                                float *d_out_partial) {
+  APSS_TRY(enter(h));
+  if (n_pairs < 0) return fail(h, APSS_E_INVALID, "negative pair count");
+  if (n_pairs == 0) return APSS_OK;
+  if (!h->last_q_rowptr) return fail(h, APSS_E_STATE, "no query batch on this handle");
+  if (!d_q_row || !d_c_slot || !d_out_partial) return fail(h, APSS_E_INVALID, "null device pointer");
+  PartialArgs a{};
+  a.n_pairs = n_pairs;
+  a.q_row = d_q_row;
+  a.c_slot = d_c_slot;
+  a.q_rowptr = h->last_q_rowptr;
+  a.q_idx = h->last_q_idx;
+  a.q_val = h->last_q_val;
+  a.c_rowptr = h->rowptr.p;
+  a.c_idx = h->idx.p;
+  a.c_val = h->val.p;
+  a.out = d_out_partial;
+  hipLaunchKernelGGL(k_partial_scores, dim3((unsigned)ceil_div(n_pairs * kGroup, 256)), dim3(256), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return APSS_OK;
+}
+
+}  // extern "C"

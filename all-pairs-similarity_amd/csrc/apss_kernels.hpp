@@ -1,0 +1,669 @@
+// apss_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4) of the all-pairs-similarity hot path.
+//
+// What each kernel restates (reference: /root/reference/core/src/main/scala/cpslab/...):
+//   k_ingest_*      client/ingest pre-filters: LoadGenerator.scala:34-37 (L2 normalise), EntryProxyActor.scala:81-93
+//                   (admission sum_i v_i >= theta), WriteWorkerActor.scala:188-194 (value > indexThreshold),
+//                   plus the term-range restriction of a multi-GPU shard
+//   k_tile_hist/scan/scatter   IndexingWorkerActor.buildInvertedIndex, IWA:61-71 (CSR rows -> per-tile posting lists)
+//   k_probe         IndexingWorkerActor.querySimilarItems, IWA:74-111 + CommonUtils.calculateSimilarity, CU:98-117
+//                   + the `sim >= similarityThreshold` prune of IWA:93
+//   k_partial_scores  CU:98-117 restricted to a shard's dims, for (q, c) pairs named by the host
+//
+// Data layout in HBM: the store is CSR (int64 rowptr, int32 idx, fp32 val, int64 ext id); the index
+// is tile-major CSC: candidate slots are cut into tiles of `cb` consecutive rows, tile T owns the posting
+// records {u32 local slot, f32 weight} of its rows grouped by term, and a u32 offset table tile_ptr[T][dim+2].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace apss {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kGroup = 16;         // lanes that share one short-segment work item (16 x 8 B = one 128-B line)
+constexpr int kItemCap = 2048;     // short-segment work items per round held in LDS
+constexpr int kLongCap = 256;      // long segments per round held in LDS
+constexpr int kLongLen = 64;       // segments longer than this are swept by the whole workgroup
+constexpr int kSurvCap = 1024;     // threshold-crossing candidates per round held in LDS
+constexpr int kProbeBlock = 1024;  // threads per probe workgroup (16 waves, one workgroup per CU)
+
+struct alignas(8) Posting {
+  uint32_t slot;  // candidate slot relative to its tile
+  float w;
+};
+
+enum Counter { kCtrResults = 0, kCtrVisits = 1, kCtrCands = 2, kCtrFlags = 3, kCtrCount = 4 };
+
+// ---------------------------------------------------------------------------------------------------------
+// wavefront ballot / prefix-sum compaction: every active lane with `pred` gets a distinct slot of a global list
+// with ONE atomic per wave (the compiler would not merge a data-dependent atomicAdd by itself).
+__device__ __forceinline__ uint64_t wave_append(bool pred, unsigned long long *counter) {
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0) return ~0ull;
+  const int lane = __lane_id();
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
+  base = __shfl(base, leader);
+  const unsigned long long below = mask & ((1ull << lane) - 1ull);
+  return pred ? base + (unsigned long long)__popcll(below) : ~0ull;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ingest
+
+struct IngestArgs {
+  int64_t n;
+  const int64_t *rowptr;  // [n+1], relative to the batch
+  const int32_t *idx;
+  const float *val;
+  int32_t dim, term_lo, term_hi;
+  uint32_t flags;  // APSS_FLAG_*
+  float theta, index_threshold;
+  // pass-1 outputs
+  int64_t *row_keep;  // [n] 0/1
+  int64_t *row_cnt;   // [n] kept entries (0 for dropped rows)
+  float *row_inv;     // [n] 1/norm (1 when not normalising)
+  float *row_sub;     // [n] L2 norm of the kept entries (the shard's sub-norm)
+  unsigned int *flags_out;  // bit0 malformed indices, bit1 non-finite value, bit2 negative value kept
+};
+
+// one 16-lane group per row
+__global__ void k_ingest_count(IngestArgs a) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  if (row >= a.n) return;
+  const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
+  unsigned bad = 0;
+  if (e < b) bad |= 1;
+  float sumsq = 0.f;
+  for (int64_t k = b + gl; k < e; k += kGroup) {
+    const float v = a.val[k];
+    const int32_t t = a.idx[k];
+    if (!(t >= 0 && t < a.dim) || (k > b && a.idx[k - 1] >= t)) bad |= 1;  // SV:75 strictly increasing, < size
+    if (!isfinite(v)) bad |= 2;
+    sumsq += v * v;
+  }
+  for (int o = kGroup / 2; o; o >>= 1) sumsq += __shfl_xor(sumsq, o, kGroup);
+  // LG:35-37: values / sqrt(foldLeft(sum + v*v))
+  const float inv = (a.flags & 4u) ? (sumsq > 0.f ? 1.0f / sqrtf(sumsq) : 0.f) : 1.0f;
+  float sum = 0.f, sub = 0.f;
+  int cnt = 0;
+  for (int64_t k = b + gl; k < e; k += kGroup) {
+    const float v = a.val[k] * inv;
+    const int32_t t = a.idx[k];
+    sum += v;  // EPA:89 with max-weight 1.0
+    const bool keep = (!(a.flags & 1u) || v > a.index_threshold) && t >= a.term_lo && t < a.term_hi;  // WWA:192
+    if (keep) {
+      cnt++;
+      sub += v * v;
+      if (v < 0.f) bad |= 4;
+    }
+  }
+  for (int o = kGroup / 2; o; o >>= 1) {
+    sum += __shfl_xor(sum, o, kGroup);
+    sub += __shfl_xor(sub, o, kGroup);
+    cnt += __shfl_xor(cnt, o, kGroup);
+    bad |= __shfl_xor(bad, o, kGroup);
+  }
+  if (gl == 0) {
+    const bool admit = !(a.flags & 2u) || sum >= a.theta;  // EPA:89
+    a.row_keep[row] = admit ? 1 : 0;
+    a.row_cnt[row] = admit ? cnt : 0;
+    a.row_inv[row] = inv;
+    a.row_sub[row] = sqrtf(sub);
+    if (bad) atomicOr(a.flags_out, bad);
+  }
+}
+
+struct IngestWriteArgs {
+  IngestArgs in;
+  const int64_t *row_dst;  // [n+1] exclusive scan of row_keep
+  const int64_t *nnz_dst;  // [n+1] exclusive scan of row_cnt
+  int64_t dst_row0, dst_nnz0;  // where the batch lands in the destination arrays
+  int64_t *o_rowptr;  // destination rowptr (absolute offsets); o_rowptr[dst_row0 + r + 1] is written
+  int32_t *o_idx;
+  float *o_val;
+  int64_t *o_ext;
+  float *o_sub;  // sub-norm per destination row (may be null)
+  const int64_t *ext;
+};
+
+__global__ void k_ingest_write(IngestWriteArgs w) {
+  const IngestArgs &a = w.in;
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  if (row >= a.n) return;
+  if (!a.row_keep[row]) return;
+  const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
+  const float inv = a.row_inv[row];
+  const int64_t dr = w.dst_row0 + w.row_dst[row];
+  int64_t out = w.dst_nnz0 + w.nnz_dst[row];
+  for (int64_t k0 = b; k0 < e; k0 += kGroup) {
+    const int64_t k = k0 + gl;
+    bool keep = false;
+    float v = 0.f;
+    int32_t t = 0;
+    if (k < e) {
+      v = a.val[k] * inv;
+      t = a.idx[k];
+      keep = (!(a.flags & 1u) || v > a.index_threshold) && t >= a.term_lo && t < a.term_hi;
+    }
+    // ordered compaction inside the 16-lane group
+    const unsigned long long m = __ballot(keep);
+    const int lane = __lane_id();
+    const int gbase = lane & ~(kGroup - 1);
+    const unsigned gm = (unsigned)((m >> gbase) & 0xffffu);
+    if (keep) {
+      const int64_t o = out + __popc(gm & ((1u << gl) - 1u));
+      w.o_idx[o] = t;
+      w.o_val[o] = v;
+    }
+    out += __popc(gm);
+  }
+  if (gl == 0) {
+    w.o_rowptr[dr + 1] = w.dst_nnz0 + w.nnz_dst[row] + a.row_cnt[row];
+    w.o_ext[dr] = w.ext[row];
+    if (w.o_sub) w.o_sub[dr] = a.row_sub[row];
+  }
+}
+
+// single-workgroup exclusive scan of int64 (n+1 outputs, out[n] = total); ingest-only, n <= a few million
+__global__ __launch_bounds__(1024) void k_scan_i64(const int64_t *in, int64_t *out, int64_t n) {
+  __shared__ int64_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t b = (int64_t)tid * per, e = b + per < n ? b + per : n;
+  int64_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += in[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int64_t v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int64_t run = part[tid] - s;
+  for (int64_t i = b; i < e; ++i) {
+    const int64_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (tid == 1023) out[n] = part[1023];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// index build (IWA:61-71): for rows [row0, row1) of the store, fill the posting lists of their tiles.
+// tile_ptr row layout (u32[dim + 2]): after k_tile_hist tp[t + 2] = df_t in the tile; k_tile_scan makes
+// tp[t + 1] = first posting of term t; k_tile_scatter's cursor increments leave tp[t] = first, tp[t + 1] = end.
+
+struct BuildArgs {
+  const int64_t *rowptr;
+  const int32_t *idx;
+  const float *val;
+  int64_t row0, row1;
+  int32_t cb;
+  int32_t dim;
+  uint32_t *tile_ptr;
+  int64_t tp_stride;  // dim + 2
+  Posting *post;      // same indexing as idx/val: tile T's postings live at [rowptr[T*cb], rowptr[min((T+1)*cb, n)))
+};
+
+// one wave per row: coalesced reads of the row's entries
+__global__ void k_tile_hist(BuildArgs a) {
+  const int64_t row = a.row0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int lane = threadIdx.x % kWave;
+  if (row >= a.row1) return;
+  uint32_t *tp = a.tile_ptr + (row / a.cb) * a.tp_stride;
+  const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
+  for (int64_t k = b + lane; k < e; k += kWave) atomicAdd(&tp[a.idx[k] + 2], 1u);
+}
+
+// one workgroup per tile: in-place inclusive scan of tp[1 .. dim+1]
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *tile_ptr, int64_t tp_stride, int32_t dim, int64_t tile0) {
+  __shared__ uint32_t part[1024];
+  uint32_t *tp = tile_ptr + (tile0 + blockIdx.x) * tp_stride + 1;
+  const int tid = threadIdx.x;
+  const int32_t n = dim + 1;
+  const int32_t per = (n + 1023) / 1024;
+  const int32_t b = tid * per, e = b + per < n ? b + per : n;
+  uint32_t s = 0;
+  for (int32_t i = b; i < e; ++i) s += tp[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    uint32_t v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - s;
+  for (int32_t i = b; i < e; ++i) {
+    run += tp[i];
+    tp[i] = run;
+  }
+}
+
+__global__ void k_tile_scatter(BuildArgs a) {
+  const int64_t row = a.row0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int lane = threadIdx.x % kWave;
+  if (row >= a.row1) return;
+  const int64_t tile = row / a.cb;
+  uint32_t *tp = a.tile_ptr + tile * a.tp_stride;
+  Posting *post = a.post + a.rowptr[tile * a.cb];
+  const uint32_t local = (uint32_t)(row - tile * a.cb);
+  const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
+  for (int64_t k = b + lane; k < e; k += kWave) {
+    const uint32_t pos = atomicAdd(&tp[a.idx[k] + 1], 1u);
+    Posting p;
+    p.slot = local;
+    p.w = a.val[k];
+    post[pos] = p;
+  }
+}
+
+// per-tile minimum of the positive shard sub-norms (threshold scale of a tile in shard mode)
+__global__ void k_tile_min_sub(const float *sub, int64_t n_rows, int32_t cb, float *tile_min, int64_t tile0) {
+  const int64_t tile = tile0 + blockIdx.x;
+  const int64_t r0 = tile * cb, r1 = r0 + cb < n_rows ? r0 + cb : n_rows;
+  float m = 3.0e38f;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+    const float v = sub[r];
+    if (v > 0.f) m = fminf(m, v);
+  }
+  __shared__ float red[1024];
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tile_min[tile] = red[0] > 1.0e38f ? 0.f : red[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// probe (IWA:74-111 + CU:98-117 + IWA:93)
+
+struct ProbeArgs {
+  // index
+  const uint32_t *tile_ptr;
+  int64_t tp_stride;
+  const Posting *post;
+  const int64_t *store_rowptr;  // tile T's postings start at post[store_rowptr[T * cb]]
+  const int64_t *ext_id;        // candidate external ids
+  const float *c_scale;         // shard sub-norm per candidate slot (null: 1)
+  const float *tile_scale;      // min positive sub-norm per tile (null: 1)
+  int64_t n_rows;
+  int32_t cb;
+  int32_t n_tiles;
+  // query batch
+  const int64_t *q_rowptr;  // offsets into q_idx / q_val
+  const int32_t *q_idx;
+  const float *q_val;
+  const int64_t *q_ext;
+  const float *q_scale;     // shard sub-norm per query row (null: 1)
+  int32_t nq;
+  int32_t q_chunk;          // queries per workgroup
+  int32_t n_chunks;
+  int64_t q_slot_base;      // slot of query row 0 when the batch is stored in the index, else -1
+  float theta;
+  // output
+  int32_t *res_q;
+  int32_t *res_c;
+  float *res_s;
+  uint64_t res_cap;
+  unsigned long long *counters;  // [kCtrCount]
+};
+
+// dynamic-LDS carve (all offsets multiples of 16 B)
+struct ProbeLds {
+  float *acc;        // [cb] fp32 accumulators of the tile's candidates
+  uint2 *items;      // [kItemCap] {first posting, count | term slot << 8}
+  uint2 *longs;      // [kLongCap] {first posting, length}
+  float *long_w;     // [kLongCap]
+  float *wq;         // [BLOCK] query weights of the current term pass
+  uint32_t *surv;    // [kSurvCap] local slots that crossed the threshold
+  uint32_t *bitmap;  // [cb / 32] touched bits (MODE 2 only)
+  uint32_t *ctr;     // [2][4]: items, longs, survivors, pad -- double-buffered by round parity
+};
+
+__host__ __device__ inline size_t probe_lds_bytes(int cb, int block, int mode) {
+  size_t b = (size_t)cb * 4 + (size_t)kItemCap * 8 + (size_t)kLongCap * 8 + (size_t)kLongCap * 4 +
+             (size_t)block * 4 + (size_t)kSurvCap * 4 + 64;
+  if (mode == 2) b += (size_t)((cb + 31) / 32 + 3) / 4 * 16;
+  return (b + 15) / 16 * 16;
+}
+
+// MODE 0: non-negative weights and a positive threshold: a candidate's running sum is monotone, so the one add
+//         that takes it across the threshold is detected from the returning LDS atomic; no accumulator scan.
+// MODE 1: general weights, positive threshold: scan all accumulators after the round.
+// MODE 2: threshold <= 0: additionally track touched candidates in an LDS bitmap (an untouched candidate is
+//         never scored by the reference even though 0 >= theta).
+template <int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ProbeLds L;
+  {
+    unsigned char *p = smem_raw;
+    L.acc = (float *)p;
+    p += (size_t)a.cb * 4;
+    L.items = (uint2 *)p;
+    p += (size_t)kItemCap * 8;
+    L.longs = (uint2 *)p;
+    p += (size_t)kLongCap * 8;
+    L.long_w = (float *)p;
+    p += (size_t)kLongCap * 4;
+    L.wq = (float *)p;
+    p += (size_t)BLOCK * 4;
+    L.surv = (uint32_t *)p;
+    p += (size_t)kSurvCap * 4;
+    L.ctr = (uint32_t *)p;
+    p += 64;
+    L.bitmap = (uint32_t *)p;
+  }
+  const int tid = threadIdx.x;
+  const int cb = a.cb;
+  const int tile = blockIdx.x / a.n_chunks;
+  const int chunk = blockIdx.x % a.n_chunks;
+  const int q0 = chunk * a.q_chunk;
+  const int q1 = min(a.nq, q0 + a.q_chunk);
+  const uint32_t *tp = a.tile_ptr + (int64_t)tile * a.tp_stride;
+  const int64_t tile_row0 = (int64_t)tile * cb;
+  const Posting *post = a.post + a.store_rowptr[tile_row0];
+  const float tile_scale = a.tile_scale ? a.tile_scale[tile] : 1.0f;
+
+  if (tid < 8) L.ctr[tid] = 0;
+  unsigned long long my_visits = 0;
+  unsigned long long my_cands = 0;  // first touches seen by this lane
+  unsigned long long my_self = 0;
+  __syncthreads();
+
+  // software pipeline of the query-side loads (each level is issued one round before it is needed, so no
+  // dependent global-load chain sits in front of a round): R = row extent, I = term + weight, P = segment
+  int64_t qb1 = 0, qe1 = 0, qb2 = 0, qe2 = 0;  // extents of rounds r+1, r+2
+  int32_t term1 = 0;
+  float w1 = 0.f;  // round r+1
+  uint32_t s0 = 0, len0 = 0;
+  float w0 = 0.f;  // round r
+  int64_t qb0 = 0, qe0 = 0;
+  if (q0 < q1) {
+    qb0 = a.q_rowptr[q0];
+    qe0 = a.q_rowptr[q0 + 1];
+    if (qb0 + tid < qe0) {
+      const int32_t t = a.q_idx[qb0 + tid];
+      w0 = a.q_val[qb0 + tid];
+      s0 = tp[t];
+      len0 = tp[t + 1] - s0;
+    }
+    if (q0 + 1 < q1) {
+      qb1 = a.q_rowptr[q0 + 1];
+      qe1 = a.q_rowptr[q0 + 2];
+      if (qb1 + tid < qe1) {
+        term1 = a.q_idx[qb1 + tid];
+        w1 = a.q_val[qb1 + tid];
+      }
+    }
+    if (q0 + 2 < q1) {
+      qb2 = a.q_rowptr[q0 + 2];
+      qe2 = a.q_rowptr[q0 + 3];
+    }
+  }
+
+  for (int q = q0; q < q1; ++q) {
+    uint32_t *ctr = L.ctr + ((q - q0) & 1) * 4;
+    const int64_t qb = qb0, qe = qe0;
+    const int nnz = (int)(qe - qb);
+    const float qs = a.q_scale ? a.q_scale[q] : 1.0f;
+    const float thr = a.theta * qs * tile_scale;
+
+    // ---- issue the next rounds' loads: P(r+1), I(r+2), R(r+3) ----
+    uint32_t s1 = 0, len1 = 0;
+    if (q + 1 < q1 && qb1 + tid < qe1) {
+      s1 = tp[term1];
+      len1 = tp[term1 + 1] - s1;
+    }
+    int32_t term2 = 0;
+    float w2 = 0.f;
+    if (q + 2 < q1 && qb2 + tid < qe2) {
+      term2 = a.q_idx[qb2 + tid];
+      w2 = a.q_val[qb2 + tid];
+    }
+    int64_t qb3 = 0, qe3 = 0;
+    if (q + 3 < q1) {
+      qb3 = a.q_rowptr[q + 3];
+      qe3 = a.q_rowptr[q + 4];
+    }
+
+    // ---- zero the tile's accumulators ----
+    {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = tid * 4; i < cb; i += BLOCK * 4) *reinterpret_cast<float4 *>(L.acc + i) = z;
+      if (MODE == 2)
+        for (int i = tid; i < (cb + 31) / 32; i += BLOCK) L.bitmap[i] = 0;
+    }
+
+    // ---- term passes (one pass unless the query has more than BLOCK terms) ----
+    for (int t0 = 0; t0 < nnz; t0 += BLOCK) {
+      uint32_t s = 0, len = 0;
+      float w = 0.f;
+      if (t0 == 0) {
+        s = s0;
+        len = len0;
+        w = w0;
+      } else {
+        __syncthreads();  // previous pass drained, its counter reset visible
+        if (t0 + tid < nnz) {
+          const int32_t t = a.q_idx[qb + t0 + tid];
+          w = a.q_val[qb + t0 + tid];
+          s = tp[t];
+          len = tp[t + 1] - s;
+        }
+      }
+      my_visits += len;
+      L.wq[tid] = w;
+      bool pending = len > 0;
+      while (true) {
+        if (pending) {
+          if (len <= (uint32_t)kLongLen) {
+            const uint32_t nch = (len + kGroup - 1) / kGroup;
+            const uint32_t base = atomicAdd(&ctr[0], nch);
+            if (base + nch <= (uint32_t)kItemCap) {
+              for (uint32_t k = 0; k < nch; ++k) {
+                const uint32_t c = min((uint32_t)kGroup, len - k * kGroup);
+                L.items[base + k] = make_uint2(s + k * kGroup, c | ((uint32_t)tid << 8));
+              }
+              pending = false;
+            } else {
+              for (uint32_t k = base; k < min(base + nch, (uint32_t)kItemCap); ++k) L.items[k] = make_uint2(0u, 0u);
+            }
+          } else {
+            const uint32_t base = atomicAdd(&ctr[1], 1u);
+            if (base < (uint32_t)kLongCap) {
+              L.longs[base] = make_uint2(s, len);
+              L.long_w[base] = w;
+              pending = false;
+            }
+          }
+        }
+        const int any_pending = __syncthreads_or(pending ? 1 : 0);
+
+        // ---- accumulate: acc[c] += w_q * w_c for every posting of every listed segment ----
+        const uint32_t n_items = min(ctr[0], (uint32_t)kItemCap);
+        const uint32_t n_long = min(ctr[1], (uint32_t)kLongCap);
+        auto visit = [&](const Posting pc, const float wq_) {
+          const float p = wq_ * pc.w;
+          if (MODE == 0) {
+            const float old = atomicAdd(&L.acc[pc.slot], p);  // ds_add_rtn_f32
+            my_cands += (old == 0.0f) ? 1u : 0u;
+            if (old < thr && old + p >= thr) {
+              const uint32_t k = atomicAdd(&ctr[2], 1u);
+              if (k < (uint32_t)kSurvCap) L.surv[k] = pc.slot;
+            }
+          } else {
+            atomicAdd(&L.acc[pc.slot], p);
+            if (MODE == 2) atomicOr(&L.bitmap[pc.slot >> 5], 1u << (pc.slot & 31));
+          }
+        };
+        const int grp = tid / kGroup, gl = tid % kGroup;
+        for (uint32_t i = grp; i < n_items; i += BLOCK / kGroup) {
+          const uint2 it = L.items[i];
+          const uint32_t cnt = it.y & 0xffu;
+          if ((uint32_t)gl < cnt) visit(post[it.x + gl], L.wq[it.y >> 8]);
+        }
+        for (uint32_t j = 0; j < n_long; ++j) {
+          const uint2 sg = L.longs[j];
+          const float wq_ = L.long_w[j];
+          for (uint32_t k = tid; k < sg.y; k += BLOCK) visit(post[sg.x + k], wq_);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          ctr[0] = 0;
+          ctr[1] = 0;
+        }
+        if (!any_pending) break;
+        __syncthreads();
+      }
+    }
+    if (nnz == 0) __syncthreads();  // keep the barrier count per round uniform for the zeroing hazard
+
+    // ---- threshold prune + compaction (IWA:93-95) ----
+    const int64_t qext = a.q_ext[q];
+    if (MODE == 0) {
+      if (a.q_slot_base >= 0) {  // the query's own slot is a touched candidate that is not a (q, c != q) pair
+        const int64_t sl = a.q_slot_base + q - tile_row0;
+        // checked by the thread that zeroes this accumulator next round (program order, no extra barrier)
+        if (sl >= 0 && sl < cb && tid == (int)((sl >> 2) % BLOCK) && L.acc[sl] != 0.0f) my_self++;
+      }
+      const uint32_t n_surv = ctr[2];
+      if (n_surv > 0) {
+        if (n_surv <= (uint32_t)kSurvCap) {
+          for (uint32_t i = tid; i < (n_surv + kWave - 1) / kWave * kWave; i += BLOCK) {
+            bool ok = false;
+            uint32_t c = 0;
+            float sc = 0.f;
+            if (i < n_surv) {
+              c = L.surv[i];
+              sc = L.acc[c];
+              const int64_t gs = tile_row0 + c;
+              ok = a.ext_id[gs] != qext && (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs]);
+            }
+            const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+            if (ok && o < a.res_cap) {
+              a.res_q[o] = q;
+              a.res_c[o] = (int32_t)(tile_row0 + c);
+              a.res_s[o] = sc;
+            }
+          }
+        } else {
+          // more crossings than the LDS list holds: fall back to the accumulator scan for this round
+          for (int i = tid; i < (cb + BLOCK - 1) / BLOCK * BLOCK; i += BLOCK) {
+            bool ok = false;
+            float sc = 0.f;
+            if (i < cb) {
+              sc = L.acc[i];
+              const int64_t gs = tile_row0 + i;
+              ok = sc >= thr && gs < a.n_rows && a.ext_id[gs] != qext &&
+                   (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs]);
+            }
+            const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+            if (ok && o < a.res_cap) {
+              a.res_q[o] = q;
+              a.res_c[o] = (int32_t)(tile_row0 + i);
+              a.res_s[o] = sc;
+            }
+          }
+        }
+        __syncthreads();  // survivors read before the next round zeroes acc / reuses the list
+        if (tid == 0) ctr[2] = 0;
+      }
+    } else {
+      for (int i = tid; i < (cb + BLOCK - 1) / BLOCK * BLOCK; i += BLOCK) {
+        bool ok = false;
+        float sc = 0.f;
+        if (i < cb) {
+          sc = L.acc[i];
+          const int64_t gs = tile_row0 + i;
+          bool touched = (MODE == 2) ? ((L.bitmap[i >> 5] >> (i & 31)) & 1u) : (sc != 0.0f);
+          if (touched && gs < a.n_rows) {
+            const bool self = a.ext_id[gs] == qext;
+            if (!self) my_cands += 1;
+            ok = !self && sc >= thr && (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs]);
+          }
+        }
+        const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+        if (ok && o < a.res_cap) {
+          a.res_q[o] = q;
+          a.res_c[o] = (int32_t)(tile_row0 + i);
+          a.res_s[o] = sc;
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- rotate the software pipeline ----
+    qb0 = qb1;
+    qe0 = qe1;
+    s0 = s1;
+    len0 = len1;
+    w0 = w1;
+    qb1 = qb2;
+    qe1 = qe2;
+    term1 = term2;
+    w1 = w2;
+    qb2 = qb3;
+    qe2 = qe3;
+  }
+
+  // ---- statistics: one atomic per workgroup (scratch lives in the dynamic carve: a static __shared__ object
+  // would shift the 16-B alignment of the accumulator array) ----
+  unsigned long long *stat = reinterpret_cast<unsigned long long *>(L.ctr + 8);
+  __syncthreads();
+  if (tid < 3) stat[tid] = 0;
+  __syncthreads();
+  atomicAdd(&stat[0], my_visits);
+  atomicAdd(&stat[1], my_cands);
+  if (my_self) atomicAdd(&stat[2], my_self);
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&a.counters[kCtrVisits], stat[0]);
+    atomicAdd(&a.counters[kCtrCands], stat[1] - stat[2]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// exact partial score of named pairs over the shard's dims (two sorted index lists, 16 lanes per pair:
+// each lane binary-searches its share of the query's entries in the candidate row)
+struct PartialArgs {
+  int64_t n_pairs;
+  const int32_t *q_row;
+  const int32_t *c_slot;
+  const int64_t *q_rowptr;
+  const int32_t *q_idx;
+  const float *q_val;
+  const int64_t *c_rowptr;
+  const int32_t *c_idx;
+  const float *c_val;
+  float *out;
+};
+
+__global__ void k_partial_scores(PartialArgs a) {
+  const int64_t pair = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  if (pair >= a.n_pairs) return;
+  const int64_t qb = a.q_rowptr[a.q_row[pair]], qe = a.q_rowptr[a.q_row[pair] + 1];
+  const int64_t cb = a.c_rowptr[a.c_slot[pair]], ce = a.c_rowptr[a.c_slot[pair] + 1];
+  float s = 0.f;
+  for (int64_t k = qb + gl; k < qe; k += kGroup) {
+    const int32_t t = a.q_idx[k];
+    int64_t lo = cb, hi = ce;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
+  }
+  for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
+  if (gl == 0) a.out[pair] = s;
+}
+
+}  // namespace apss

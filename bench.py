@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's hot path (inverted-index probe + candidate scoring + threshold prune) on MI355X.
+
+A step is one pass of the hot path over one batch: the IndexData handler on the whole synthetic batch
+(IndexingWorkerActor.scala:123-137 = build the index from the batch, then query the batch against it: a
+single-batch self-join), inputs already resident in HBM.  Workload = BASELINE.json configs[2] "Synthetic N=1M,
+dim=100k, nnz=100, cosine theta=0.8" (the configuration the metric is quoted on); --workload picks another.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (term-range shards, RCCL)
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "all-pairs-similarity_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # ... 6.29 TB/s measured float4 copy
+BYTES_PER_VISIT = 8            # one posting = int32 slot + fp32 weight
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", help="c2 | c3 | c3z (BASELINE.json configs; c3 is the metric's)")
+    ap.add_argument("--n", type=int, default=None, help="override the number of vectors (debug)")
+    ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, rp, idx, val, budget_s):
+    """The oracle's restatement of the reference algorithm ("port": posting lists + the per-candidate hash-map dot
+    of CommonUtils.scala:98-117 in double), timed on this box's host cores on a bounded query sample."""
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = len(rp) - 1
+    pilot_q = min(n, cores * 2)
+    p = oracle.selfjoin_sample(0, cfg["dim"], cfg["theta"], rp, idx, val, 0, pilot_q, cores)
+    per_q = max(p["seconds"] / max(pilot_q, 1), 1e-7)
+    sample = int(min(n, max(pilot_q, budget_s / per_q)))
+    r = oracle.selfjoin_sample(0, cfg["dim"], cfg["theta"], rp, idx, val, 0, sample, cores)
+    opt = oracle.selfjoin_sample(1, cfg["dim"], cfg["theta"], rp, idx, val, 0, min(n, sample * 20), cores)
+    return {
+        "value": r["cand_pairs"] / r["seconds"], "unit": "scored candidate pairs/s", "cores": cores, "kind": "port",
+        "sample": "all %d vectors indexed, first %d queries timed (%.1f s, %d threads); reference algorithm: posting "
+                  "lists + per-candidate HashMap dot in double" % (n, sample, r["seconds"], cores),
+        "optimised_cpu_value": opt["cand_pairs"] / opt["seconds"],
+        "optimised_cpu_note": "fairness bracket: CSC + dense double accumulator, %d threads" % cores,
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from apss import synth
+    from apss.engine import ApssIndex
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = dict(synth.CONFIGS[a.workload])
+    if a.n:
+        cfg["n"] = a.n
+    t0 = time.time()
+    rp, idx, val = synth.make_vectors(cfg["n"], cfg["dim"], cfg["nnz"], cfg["zipf_s"], cfg["seed"])
+    gen_s = time.time() - t0
+    n = cfg["n"]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if world == 1:
+        d_rp = torch.from_numpy(rp).to(dev)
+        d_idx = torch.from_numpy(idx).to(dev)
+        d_val = torch.from_numpy(val.astype(np.float32)).to(dev)
+        d_ids = torch.arange(n, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()  # the library runs on its own stream
+        ix = ApssIndex(cfg["dim"], cfg["theta"], device=local_rank, tile_rows=a.tile_rows, capacity_rows=n,
+                       capacity_nnz=idx.size)
+
+        def step():
+            ix.clear()
+            return ix.insert_and_query_dev(d_ids, d_rp, d_idx, d_val)
+
+        probe_ms, build_ms = [], []
+        for _ in range(a.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            n_pairs = step()
+            st = ix.stats()
+            probe_ms.append(st["probe_ms"])
+            build_ms.append(st["build_ms"])
+        sync()
+        dt = time.perf_counter() - t0
+        visits, cands = st["posting_visits"], st["candidate_pairs"]
+        launches = st["probe_launches"]
+        parallelism = "1 GPU"
+        extra = {}
+    else:
+        from apss.dist import ShardedJoin
+        sj = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows)
+        sj.load(rp, idx, val)
+        probe_ms, build_ms = [], []
+        for _ in range(a.warmup):
+            sj.step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            n_pairs = sj.step()
+            probe_ms.append(sj.last["probe_ms"])
+            build_ms.append(sj.last["build_ms"])
+        sync()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        visits, cands, launches = sj.last["posting_visits"], sj.last["candidate_pairs"], 1
+        parallelism = "term-range shards x%d, candidate all-gather + RCCL all-reduce of partial scores" % world
+        extra = {"exchange": sj.last.get("exchange")}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    sec_per_step = dt / a.steps
+    kern_s = float(np.mean(probe_ms)) * 1e-3
+    alg_bytes = BYTES_PER_VISIT * visits
+    out = {
+        "metric": "scored candidate pairs/sec + achieved HBM GB/s, N=1M d=100k nnz=100, 1/2/4/8 GPU",
+        "value": cands / sec_per_step,
+        "unit": "scored candidate pairs/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": sec_per_step * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s: N=%d dim=%d nnz=%d %s theta=%g, single-batch self-join (build + probe)" % (
+            a.workload, n, cfg["dim"], cfg["nnz"], "Zipf(%g)" % cfg["zipf_s"] if cfg["zipf_s"] else "uniform",
+            cfg["theta"]), "parallelism": parallelism, "tile_rows": a.tile_rows or 32768},
+        "posting_visits_per_step": visits,
+        "candidate_pairs_per_step": cands,
+        "result_pairs_per_step": int(n_pairs),
+        "posting_visits_per_s": visits / sec_per_step,
+        "algorithmic_GBps_whole_step": alg_bytes / sec_per_step / 1e9,
+        "build_ms": float(np.mean(build_ms)),
+        "probe_kernel_ms": float(np.mean(probe_ms)),
+        "datagen_s": gen_s,
+        "roofline": {
+            "bound": "hbm", "kernel": "k_probe",
+            "achieved": alg_bytes / launches / kern_s / 1e9 if kern_s > 0 else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (alg_bytes / launches / kern_s / 1e9) / HBM_PEAK_GBS if kern_s > 0 else None,
+            "frac_of_measured_copy_peak": (alg_bytes / launches / kern_s / 1e9) / HBM_COPY_GBS if kern_s > 0 else None,
+            "traffic": None,
+            "note": "achieved = 8 B x posting visits per launch / HIP-event kernel time on the launch stream",
+        },
+    }
+    out.update(extra)
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds)
+    elif not a.no_cpu_baseline:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

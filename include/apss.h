@@ -1,0 +1,147 @@
+/*
+ * apss.h -- C ABI of the MI355X-native all-pairs-similarity hot path (libapss_hip.so).
+ *
+ * Drop-in boundary.  The reference (mcgill-cpslab/all-pairs-similarity, Scala/Akka) has no FFI of its own;
+ * the seam this library replaces is the `case IndexData(vectors)` handler of one IndexingWorkerActor
+ *     core/src/main/scala/cpslab/deploy/server/IndexingWorkerActor.scala:123-137
+ * i.e. buildInvertedIndex (IWA:61-71) + querySimilarItems (IWA:74-111) + CommonUtils.calculateSimilarity
+ * (core/src/main/scala/cpslab/deploy/CommonUtils.scala:98-117), with SparkSparseVector (size, indices:
+ * Array[Int], values: Array[Double]) in and the SimilarityOutput map (message/Message.scala:20-21) out.
+ * A JNI shim (all-pairs-similarity_amd/jvm/) forwards 1:1 to these entry points; see INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int32 status (0 = ok, < 0 = error,
+ * text via apss_last_error); nothing throws or calls back across the boundary; inputs are caller-owned and
+ * consumed before return; results stay in the handle until the next query-type call and are copied out
+ * with apss_fetch_results (two-call pattern: ask for the count, then fetch).
+ * Threading mirrors the actor model: at most one thread inside a given handle at a time, different handles
+ * may be used concurrently; the library sets the device on every entry and owns one HIP stream per handle.
+ *
+ * Semantics: "intended" semantics of the reference -- exact threshold join
+ * sim(q, c) = sum_i q_i * c_i >= theta (inclusive, IWA:93) over every candidate c sharing >= 1 indexed term
+ * with q, self-exclusion by EXTERNAL id (IWA:91), each (q, c) reported once (the reference's duplicate
+ * reports across term workers, IWA:105 "TODO: need to deduplicate", are collapsed).  The reference's
+ * first-dim skip quirk (IWA:89 vs 106) is NOT reproduced on the device; it is restated only in oracle/.
+ * Scores are accumulated in fp32 on the device (reference: double): |score - double| <= 1e-5 and set
+ * membership may differ only for |score - theta| <= 1e-5.
+ */
+#ifndef APSS_H
+#define APSS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APSS_OK 0
+#define APSS_E_INVALID (-1)     /* bad argument / malformed vector: the IllegalArgumentException of `require`
+                                   (CommonUtils.scala:99, vector/SparseVector.scala:75,202) */
+#define APSS_E_NOMEM (-2)       /* host or device allocation failed */
+#define APSS_E_DEVICE (-3)      /* HIP runtime error (no GPU, launch failure, ...) */
+#define APSS_E_STATE (-4)       /* call not valid in this state (e.g. fetch before any query) */
+#define APSS_E_UNSUPPORTED (-5) /* option not supported by this build */
+
+/* apss_config.flags */
+#define APSS_FLAG_VALUE_PRUNE 1u /* drop entries with value <= index_threshold before indexing, no
+                                    re-normalisation (WriteWorkerActor.scala:188-194) */
+#define APSS_FLAG_ADMISSION 2u   /* admit a vector only if sum_i v_i >= theta (EntryProxyActor.scala:81-93,
+                                    max-weight == 1.0 per EntryProxyActor.scala:51-57) */
+#define APSS_FLAG_NORMALIZE 4u   /* L2-normalise rows on ingest (benchmark/LoadGenerator.scala:34-37) */
+#define APSS_FLAG_FORCE_SCAN 8u  /* always use the general accumulator-scan kernel (signed weights path) */
+
+typedef struct apss_handle apss_handle;
+
+typedef struct apss_config {
+  int32_t struct_size;     /* sizeof(apss_config), for ABI evolution */
+  int32_t dim;             /* cpslab.allpair.vectorDim: every vector's `size` (CU:99) */
+  double theta;            /* cpslab.allpair.similarityThreshold (IWA:23) */
+  double index_threshold;  /* cpslab.allpair.indexThreshold (WWA:35), used with APSS_FLAG_VALUE_PRUNE */
+  uint32_t flags;          /* APSS_FLAG_* */
+  int32_t device_id;       /* HIP device ordinal */
+  int32_t term_lo;         /* term-range shard [term_lo, term_hi): only these dims are indexed and scored */
+  int32_t term_hi;         /*   (0, 0) or (0, dim) = the whole term space (single GPU) */
+  int32_t tile_rows;       /* candidate tile = rows whose fp32 accumulators share one workgroup's LDS;
+                              0 = default (32768); must be a multiple of 64 and <= 32768 */
+  int32_t reserved0;
+  int64_t capacity_rows;   /* hints for the initial HBM reservation (0 = grow on demand) */
+  int64_t capacity_nnz;
+} apss_config;
+
+typedef struct apss_stats {
+  int64_t rows;             /* vectors in the store */
+  int64_t nnz;              /* postings in the index */
+  int64_t tiles;            /* candidate tiles */
+  int64_t posting_visits;   /* (query, term, posting) FMAs of the last query-type call */
+  int64_t candidate_pairs;  /* distinct (q, c != q) pairs scored by the last query-type call */
+  int64_t result_pairs;     /* pairs >= theta of the last query-type call */
+  double probe_ms;          /* device time of the last call's probe kernel(s), HIP events */
+  double build_ms;          /* device time of the last insert's index build, HIP events */
+  int64_t probe_launches;   /* probe kernel launches of the last call (re-runs after a result-buffer growth count) */
+  int64_t hbm_bytes;        /* device bytes currently reserved by the handle */
+} apss_stats;
+
+/* ---- lifetime (actor construction / stop, IWA:21-39) ---- */
+int32_t apss_create(const apss_config *cfg, apss_handle **out);
+void apss_destroy(apss_handle *h);
+/* message of the last failing call on this handle ("" if none); h == NULL: last apss_create failure */
+const char *apss_last_error(const apss_handle *h);
+/* Use a caller-owned HIP stream (hipStream_t as void*) instead of the handle's own; NULL restores it. */
+int32_t apss_set_stream(apss_handle *h, void *hip_stream);
+
+/* ---- host-pointer entry points (what the JNI shim binds) ----
+ * CSR batch: n rows; row i = indices[rowptr[i] .. rowptr[i+1]) strictly increasing in [0, dim), values alike
+ * (doubles, as SparkSparseVector.values), ext_ids[i] = the caller's integer handle for the String id. */
+
+/* buildInvertedIndex(batch), IWA:61-71 */
+int32_t apss_insert(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices,
+                    const double *values, const int64_t *ext_ids);
+/* querySimilarItems(batch) on a frozen index (stopUpdateIndex, IWA:125-127); unseen dims are empty lists */
+int32_t apss_query(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices,
+                   const double *values, const int64_t *ext_ids, int64_t *n_results);
+/* the IndexData handler: build, then query; the batch sees itself and everything before it (IWA:125-133) */
+int32_t apss_insert_and_query(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices,
+                              const double *values, const int64_t *ext_ids, int64_t *n_results);
+/* query every stored vector against the whole index (single-batch self-join, the benchmark driver) */
+int32_t apss_self_join(apss_handle *h, int64_t *n_results);
+
+/* results of the last query-type call: (query ext id, candidate ext id, score); order unspecified */
+int32_t apss_result_count(const apss_handle *h, int64_t *n_results);
+int32_t apss_fetch_results(apss_handle *h, int64_t offset, int64_t count, int64_t *out_q, int64_t *out_c,
+                           float *out_score);
+
+int32_t apss_size(const apss_handle *h, int64_t *rows, int64_t *nnz);
+int32_t apss_stats_get(apss_handle *h, apss_stats *out);
+
+/* ---- device-pointer entry points (inputs already resident in HBM: bench.py, multi-GPU host code) ----
+ * d_rowptr int64[n+1] (relative to the batch: d_rowptr[0] == 0), d_indices int32[nnz], d_values float[nnz],
+ * d_ext_ids int64[n]; all on the handle's device.  Work is enqueued on the handle's stream; the calls that
+ * return counts synchronise that stream. */
+int32_t apss_insert_dev(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr,
+                        const int32_t *d_indices, const float *d_values, const int64_t *d_ext_ids);
+int32_t apss_query_dev(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr,
+                       const int32_t *d_indices, const float *d_values, const int64_t *d_ext_ids,
+                       int64_t *n_results);
+int32_t apss_insert_and_query_dev(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr,
+                                  const int32_t *d_indices, const float *d_values, const int64_t *d_ext_ids,
+                                  int64_t *n_results);
+/* drop the index and the store, keep the reservation (lets a benchmark step re-run build + join) */
+int32_t apss_clear(apss_handle *h);
+/* device views of the last results: int32 query row (within the last query batch), int32 candidate slot,
+ * float score; valid until the next query-type call */
+int32_t apss_results_dev(apss_handle *h, const int32_t **d_q_row, const int32_t **d_c_slot,
+                         const float **d_score, int64_t *n_results);
+
+/* ---- term-range shards (multi-GPU; one handle per GPU owning dims [term_lo, term_hi)) ----
+ * Phase 1, local: a query-type call on a shard handle reports CANDIDATES, pairs whose local partial score
+ * p_g satisfies p_g >= theta * |q_g| * |c_g| (|x_g| = L2 norm of x restricted to the shard's dims).  Every
+ * pair with total score >= theta passes this test on at least one shard (Cauchy-Schwarz).
+ * Phase 2: the host unions the candidate lists of all shards, every shard fills its exact partial score for
+ * each pair with apss_partial_scores_dev, the partials are summed across GPUs (RCCL all-reduce) and
+ * thresholded.  Pairs are (query row of the last query batch, candidate slot). */
+int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *d_q_row,
+                                const int32_t *d_c_slot, float *d_out_partial);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APSS_H */

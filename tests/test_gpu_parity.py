@@ -1,0 +1,234 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same seeded
+inputs, against the committed golden fixtures, and through size-independent properties.
+Tolerances (BASELINE.json north_star): same pair set except inside |score - theta| <= 1e-5, scores within 1e-5."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from apss import synth
+from helpers import assert_same_pairs, to_map, topk
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def apss_mod():
+    from apss import _lib, engine
+    _lib.lib()  # raises if the HIP library is missing: no fallback
+    return engine
+
+
+def _gpu_join(engine, dim, theta, rp, idx, val, ids=None, **kw):
+    n = len(rp) - 1
+    ids = np.arange(n) if ids is None else ids
+    with engine.ApssIndex(dim, theta, **kw) as ix:
+        q, c, s = ix.insert_and_query(ids, rp, idx, val)
+        st = ix.stats()
+    return to_map(q, c, s), st
+
+
+def test_kat_section33_through_abi(apss_mod):
+    with open(os.path.join(GOLDEN, "kat_section33.json")) as f:
+        k = json.load(f)
+    names = ["v1", "v2", "v3", "v4", "v5"]
+    rp, idx, val = [0], [], []
+    for nm in names:
+        v = k["vectors"][nm]
+        ks = sorted(int(x) for x in v)
+        idx += ks
+        val += [v[str(x)] for x in ks]
+        rp.append(len(idx))
+    ids = np.array([int(nm[1:]) for nm in names])
+    got, st = _gpu_join(apss_mod, k["dim"], k["theta"], np.array(rp), np.array(idx, np.int32), np.array(val), ids,
+                        tile_rows=64)
+    want = {(int(q[1:]), int(c[1:])): s for q, m in k["single_batch"]["intended"].items() for c, s in m.items()}
+    assert_same_pairs(got, want, k["theta"])
+    assert st["rows"] == 5 and st["nnz"] == 7
+
+
+@pytest.mark.parametrize("name", ["mini_uniform_t03", "mini_zipf_t05", "mini_zipf_t08"])
+@pytest.mark.parametrize("tile_rows", [256, 1024, 0])
+def test_golden_fixture(apss_mod, name, tile_rows):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dim, theta = int(z["dim"]), float(z["theta"])
+    got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=tile_rows)
+    want = to_map(z["out_q"], z["out_c"], z["out_sim"])
+    assert_same_pairs(got, want, theta)
+    # top-k (first k by (-score, q, c)): equal sets imply equal top-k up to score ties inside 1e-5
+    assert {k for k, _ in topk(got, 20)} <= set(want)
+    # work counters: posting visits of a self-join = sum_t df_t^2
+    _, visits = synth.workload_counts(dim, z["rowptr"], z["indices"])
+    assert st["posting_visits"] == int(visits)
+
+
+@pytest.mark.parametrize("flags_name", ["fast", "force_scan"])
+def test_scan_path_equals_crossing_path(apss_mod, oracle, flags_name):
+    from apss import _lib
+    n, dim, nnz, theta = 1500, 300, 12, 0.45
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=21, dup_frac=0.1)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=512,
+                        flags=_lib.FLAG_FORCE_SCAN if flags_name == "force_scan" else 0)
+    assert len(want) > 100
+    assert_same_pairs(got, want, theta)
+    # candidate pairs scored == distinct (q, c != q) sharing a term
+    cands = oracle.selfjoin_sample(1, dim, theta, rp, idx, val, 0, n, 2)["cand_pairs"]
+    assert st["candidate_pairs"] == cands
+
+
+def test_signed_weights_and_nonpositive_threshold(apss_mod, oracle):
+    n, dim, nnz = 800, 200, 10
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.5, seed=22, dup_frac=0.1)
+    rng = np.random.default_rng(1)
+    sval = val * rng.choice([-1.0, 1.0], size=val.size)
+    for theta, v in ((0.3, sval), (0.0, val), (-0.2, sval)):
+        w = oracle.Worker(dim, theta)
+        want = to_map(*w.index_data(np.arange(n), rp, idx, v))
+        got, _ = _gpu_join(apss_mod, dim, theta, rp, idx, v, tile_rows=256)
+        assert len(want) > 50
+        assert_same_pairs(got, want, theta)
+
+
+def test_streaming_batches_match_oracle_worker(apss_mod, oracle):
+    n, dim, nnz, theta, b = 2400, 400, 14, 0.4, 700
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=23, dup_frac=0.1)
+    w = oracle.Worker(dim, theta)
+    with apss_mod.ApssIndex(dim, theta, tile_rows=512) as ix:
+        for b0 in range(0, n, b):
+            b1 = min(n, b0 + b)
+            sl = slice(rp[b0], rp[b1])
+            args = (np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])
+            want = to_map(*w.index_data(*args))
+            got = to_map(*ix.insert_and_query(*args))
+            assert_same_pairs(got, want, theta)
+        assert ix.size() == (n, n * nnz)
+        # frozen index (stopUpdateIndex, IWA:125-127): query-only, unseen dims are empty lists
+        qrp, qidx, qval = synth.make_vectors(50, dim, nnz, 1.0, seed=24, dup_frac=0)
+        want = to_map(*w.index_data(np.arange(50) + 10 ** 6, qrp, qidx, qval, query_only=True))
+        got = to_map(*ix.query(np.arange(50) + 10 ** 6, qrp, qidx, qval))
+        assert_same_pairs(got, want, theta)
+        assert ix.size() == (n, n * nnz)
+        # and the whole-store self-join equals the single-batch oracle
+        whole = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+        assert_same_pairs(to_map(*ix.self_join()), whole, theta)
+
+
+def test_ragged_empty_and_long_rows(apss_mod, oracle):
+    """empty batch, empty rows, a row with more terms than a workgroup has threads (multi-pass), a term shared by
+    every vector (workgroup-wide sweep), > kItemCap short segments in one round (list overflow sub-rounds)"""
+    dim, theta = 3000, 0.2
+    rng = np.random.default_rng(3)
+    rows = []
+    for i in range(900):
+        k = int(rng.integers(0, 40))
+        if i % 97 == 0:
+            k = 0
+        if i in (5, 450):
+            k = 2600  # > 1024 terms and > 2048 work items
+        t = np.sort(rng.choice(dim - 1, size=k, replace=False)) + 1
+        t = np.concatenate([[0], t]) if i % 3 else t  # dim 0 in 2/3 of the rows -> long posting list
+        v = np.abs(rng.standard_normal(t.size)) + 0.05
+        rows.append((t.astype(np.int32), v / max(np.sqrt((v * v).sum()), 1e-30)))
+    rp = np.concatenate([[0], np.cumsum([r[0].size for r in rows])])
+    idx = np.concatenate([r[0] for r in rows])
+    val = np.concatenate([r[1] for r in rows])
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    for tr in (64, 512):
+        got, _ = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=tr)
+        assert_same_pairs(got, want, theta)
+    with apss_mod.ApssIndex(dim, theta) as ix:
+        e = np.zeros(0)
+        assert ix.insert_and_query(e, [0], e, e)[0].size == 0
+        assert ix.query(e, [0], e, e)[0].size == 0
+        assert ix.self_join()[0].size == 0
+        assert ix.size() == (0, 0)
+
+
+def test_ext_id_semantics(apss_mod):
+    # self-exclusion is by external id (IWA:91): same id stored twice never matches itself; equal vectors
+    # under different ids match
+    with apss_mod.ApssIndex(4, 0.5, tile_rows=64) as ix:
+        q, c, s = ix.insert_and_query([7, 7, 8], [0, 1, 2, 3], [2, 2, 2], [1.0, 1.0, 1.0])
+        got = {(int(a), int(b)) for a, b in zip(q, c)}
+        assert got == {(7, 8), (8, 7)}
+        assert np.allclose(s, 1.0)
+
+
+def test_error_codes(apss_mod):
+    from apss import _lib
+    with apss_mod.ApssIndex(8, 0.5) as ix:
+        with pytest.raises(apss_mod.ApssError) as e:
+            ix.insert([1], [0, 2], [3, 3], [0.5, 0.5])  # not strictly increasing (SV:75)
+        assert e.value.code == _lib.E_INVALID
+        with pytest.raises(apss_mod.ApssError) as e:
+            ix.insert([1], [0, 1], [8], [1.0])  # index >= vectorDim (the require of CU:99 / SV:105)
+        assert e.value.code == _lib.E_INVALID
+        with pytest.raises(apss_mod.ApssError) as e:
+            ix.insert([1], [0, 1], [2], [float("nan")])
+        assert e.value.code == _lib.E_INVALID
+        assert ix.size() == (0, 0)  # failed batches leave no trace
+        ix.insert([1], [0, 1], [2], [1.0])
+        assert ix.size() == (1, 1)
+    with pytest.raises(apss_mod.ApssError):
+        apss_mod.ApssIndex(0, 0.5)
+    with pytest.raises(apss_mod.ApssError):
+        apss_mod.ApssIndex(8, 0.5, tile_rows=100)
+
+
+def test_ingest_prefilters(apss_mod, oracle):
+    """value prune (WWA:188-194), admission (EPA:81-93) and L2 normalisation (LG:34-37) on the device"""
+    from apss import _lib
+    n, dim, nnz, theta = 1200, 256, 12, 0.5
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=31, dup_frac=0.1)
+    raw = val * np.repeat(np.random.default_rng(2).uniform(0.5, 3.0, n), nnz)  # un-normalised input
+    ids = np.arange(n)
+    nv = oracle.l2_normalize(rp, raw)
+    # normalise -> prune -> index
+    prp, pidx, pval = oracle.value_prune(rp, idx, nv, 0.1)
+    assert pidx.size < idx.size
+    want = to_map(*oracle.Worker(dim, theta).index_data(ids, prp, pidx, pval))
+    assert len(want) > 30
+    with apss_mod.ApssIndex(dim, theta, tile_rows=256, index_threshold=0.1,
+                            flags=_lib.FLAG_NORMALIZE | _lib.FLAG_VALUE_PRUNE) as ix:
+        got = to_map(*ix.insert_and_query(ids, rp, idx, raw))
+        assert ix.size() == (n, pidx.size)
+    assert_same_pairs(got, want, theta)
+    # admission: sum_i v_i >= theta decides whether a vector is stored at all
+    theta_a = 2.9
+    keep = oracle.admission(rp, nv, theta_a)
+    assert 0 < keep.sum() < n
+    with apss_mod.ApssIndex(dim, theta_a, tile_rows=256, flags=_lib.FLAG_NORMALIZE | _lib.FLAG_ADMISSION) as ix:
+        ix.insert(ids, rp, idx, raw)
+        assert ix.size()[0] == int(keep.sum())
+
+
+def test_c2_shape_reduced(apss_mod, oracle):
+    """BASELINE config 2 shape (dim 10k, nnz 50, Zipf(1), theta 0.5) at N = 20k, default 32768-row tiles and 8192"""
+    n, dim, nnz, theta = 20000, 10000, 50, 0.5
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=synth.CONFIGS["c2"]["seed"])
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 500
+    for tr in (0, 8192):
+        got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=tr)
+        assert_same_pairs(got, want, theta)
+        assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
+
+
+def test_c3_shape_properties(apss_mod):
+    """BASELINE config 3 shape (dim 100k, nnz 100, uniform, theta 0.8) at N = 200k: size-independent properties
+    -- symmetric result set inside one batch, every score in [theta - 1e-5, 1 + 1e-5], posting visits equal
+    sum_t df_t^2, and the same set from a different tiling."""
+    n, dim, nnz, theta = 200_000, 100_000, 100, 0.8
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=synth.CONFIGS["c3"]["seed"])
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val)
+    assert len(got) > 1000
+    assert all((c, q) in got for (q, c) in got)
+    s = np.array(list(got.values()))
+    assert s.min() >= theta - 1e-5 and s.max() <= 1 + 1e-5
+    assert max(abs(got[(q, c)] - got[(c, q)]) for (q, c) in got) <= 2e-6
+    assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
+    got2, _ = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=16384)
+    assert_same_pairs(got2, got, theta, tol=2e-6)
