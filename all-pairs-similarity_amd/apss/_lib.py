@@ -8,7 +8,7 @@ CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 SO_PATH = os.path.join(CSRC, "libapss_hip.so")
 
 OK, E_INVALID, E_NOMEM, E_DEVICE, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-FLAG_VALUE_PRUNE, FLAG_ADMISSION, FLAG_NORMALIZE, FLAG_FORCE_SCAN = 1, 2, 4, 8
+FLAG_VALUE_PRUNE, FLAG_ADMISSION, FLAG_NORMALIZE, FLAG_FORCE_SCAN, FLAG_FORCE_GENERAL = 1, 2, 4, 8, 16
 
 # every symbol include/apss.h declares (tests check the library exports all of them)
 SYMBOLS = [

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -39,6 +40,8 @@ struct apss_handle {
   std::string err;
   bool sharded = false;
   bool nonneg = true;  // every stored / queried weight so far is >= 0
+  int64_t store_max_nnz = 0, q_max_nnz = 0;  // longest row of the store / of the staged query batch
+  float store_max_norm2 = 0.f, q_max_norm2 = 0.f;  // largest squared row norm (bounds every partial score)
   int32_t cb = 32768;
 
   // store (CSR) -- vectorsStore, IWA:22
@@ -68,7 +71,7 @@ struct apss_handle {
   const int32_t *last_q_idx = nullptr;
   const float *last_q_val = nullptr;
   int64_t last_nq = 0;
-  DevBuf<unsigned long long> counters;
+  DevBuf<unsigned long long> counters, dbg;
   DevBuf<unsigned int> flagword;
   // stats
   apss_stats st{};
@@ -173,7 +176,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   // destination
   int64_t dst_row0 = to_store ? h->n_rows : 0, dst_nnz0 = to_store ? h->nnz : 0;
   int64_t kept_rows = n, kept_nnz = nnz;
-  unsigned int flags_host = 0;
+  unsigned int flags_host[3] = {0, 0, 0};
   if (transform) {
     APSS_TRY(ensure(h, h->s_rowdst, (size_t)n + 1));
     APSS_TRY(ensure(h, h->s_nnzdst, (size_t)n + 1));
@@ -183,13 +186,22 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
     HIPCHK(h, hipMemcpyAsync(&kept_rows, h->s_rowdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&kept_nnz, h->s_nnzdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   }
-  HIPCHK(h, hipMemcpyAsync(&flags_host, h->flagword.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(flags_host, h->flagword.p, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (flags_host & 1u)
+  if (flags_host[0] & 1u)
     return fail(h, APSS_E_INVALID, "malformed vector: indices must be strictly increasing and in [0, dim) "
                                    "(SparseVector.scala:75; vectorDim mismatch is the require of CommonUtils.scala:99)");
-  if (flags_host & 2u) return fail(h, APSS_E_INVALID, "non-finite value in a vector");
-  if (flags_host & 4u) h->nonneg = false;
+  if (flags_host[0] & 2u) return fail(h, APSS_E_INVALID, "non-finite value in a vector");
+  if (flags_host[0] & 4u) h->nonneg = false;
+  float norm2;
+  std::memcpy(&norm2, &flags_host[2], sizeof(float));
+  if (to_store) {
+    h->store_max_nnz = std::max<int64_t>(h->store_max_nnz, flags_host[1]);
+    h->store_max_norm2 = std::max(h->store_max_norm2, norm2);
+  } else {
+    h->q_max_nnz = flags_host[1];
+    h->q_max_norm2 = norm2;
+  }
 
   DevBuf<int64_t> &o_rowptr = to_store ? h->rowptr : h->q_rowptr;
   DevBuf<int64_t> &o_ext = to_store ? h->ext : h->q_ext;
@@ -238,7 +250,7 @@ int32_t build_tiles(apss_handle *h, int64_t row0) {
   const int64_t n_tiles = ceil_div(h->n_rows, cb);
   const int64_t stride = (int64_t)h->cfg.dim + 2;
   APSS_TRY(ensure(h, h->tile_ptr, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
-  if (h->post.cap < (size_t)std::max<int64_t>(h->nnz, 1)) return fail(h, APSS_E_STATE, "postings not reserved");
+  if (h->post.cap < (size_t)h->nnz + 64) return fail(h, APSS_E_STATE, "postings not reserved");
   if (h->sharded) APSS_TRY(ensure(h, h->tile_min, (size_t)n_tiles, (size_t)tile0));
   h->n_tiles = n_tiles;
   if (n_tiles == tile0) return APSS_OK;
@@ -276,7 +288,7 @@ int32_t build_tiles(apss_handle *h, int64_t row0) {
 
 // the store's postings array must keep earlier tiles when it is reallocated: ensure() with keep
 int32_t reserve_postings(apss_handle *h, int64_t new_nnz, int64_t keep_nnz) {
-  return ensure(h, h->post, (size_t)std::max<int64_t>(new_nnz, 1), (size_t)keep_nnz);
+  return ensure(h, h->post, (size_t)new_nnz + 64, (size_t)keep_nnz);  // + pad: clamped prefetch loads may read post[end]
 }
 
 template <int MODE>
@@ -290,7 +302,8 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
 
 // ---- probe the whole index with a query batch resident on the device ----
 int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t *q_idx, const float *q_val,
-              const int64_t *q_ext, const float *q_sub, int64_t q_slot_base, int64_t *n_results) {
+              const int64_t *q_ext, const float *q_sub, int64_t q_slot_base, int64_t q_max_nnz, float q_max_norm2,
+              int64_t q_nnz_end, int64_t *n_results) {
   h->res_q_ext = q_ext;
   h->last_q_rowptr = q_rowptr;
   h->last_q_idx = q_idx;
@@ -302,7 +315,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.probe_launches = 0;
   if (n_results) *n_results = 0;
   APSS_TRY(ensure(h, h->counters, kCtrCount));
-  if (nq == 0 || h->n_tiles == 0) return APSS_OK;
+  if (nq == 0 || h->n_tiles == 0 || q_nnz_end <= 0 || h->nnz == 0) return APSS_OK;  // nothing can share a term
   if (nq > 0x7fffffffLL) return fail(h, APSS_E_INVALID, "query batch too large");
 
   const double theta = h->cfg.theta;
@@ -328,6 +341,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.q_ext = q_ext;
   a.q_scale = h->sharded ? q_sub : nullptr;
   a.nq = (int32_t)nq;
+  a.q_nnz_end = q_nnz_end;
   // ~2 workgroups per CU per tile in flight at once, tiles swept one after another (tile-major grid) so the
   // chip works on one tile's postings at a time and they stay in L2 / Infinity Cache
   const int64_t want_chunks = 512;
@@ -336,7 +350,15 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.q_slot_base = q_slot_base;
   a.theta = (float)theta;
   a.counters = h->counters.p;
-  const size_t lds = probe_lds_bytes(h->cb, kProbeBlock, mode);
+  // speed path: per-wave flattened segments + prefetch + touched-slot re-zeroing (k_probe_wave)
+  // Fixed-point accumulators need every partial score to fit: by Cauchy-Schwarz a partial sum of non-negative
+  // products is at most |q| * |c| <= the product of the largest row norms.
+  const double bound = std::sqrt((double)q_max_norm2) * std::sqrt((double)h->store_max_norm2) * 1.0001 + 1e-6;
+  const double fx_scale = bound < 3.9 ? 1073741824.0 : (bound < 15.6 ? 268435456.0 : 0.0);
+  const bool wave_path = mode == 0 && fx_scale > 0 && q_max_nnz <= kProbeBlock && !(h->cfg.flags & APSS_FLAG_FORCE_GENERAL);
+  a.fx_scale = (float)fx_scale;
+  a.theta_fx = (uint32_t)std::min(4294967295.0, std::ceil(theta * fx_scale));
+  const size_t lds = wave_path ? probe_wave_lds_bytes(h->cb) : probe_lds_bytes(h->cb, kProbeBlock, mode);
 
   if (h->res_q.cap == 0) {
     const size_t cap0 = 1u << 20;
@@ -345,13 +367,37 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     APSS_TRY(ensure(h, h->res_s, cap0, 0, true));
   }
   for (int attempt = 0; attempt < 3; ++attempt) {
+    a.dbg = nullptr;
     a.res_q = h->res_q.p;
     a.res_c = h->res_c.p;
     a.res_s = h->res_s.p;
     a.res_cap = h->res_q.cap;
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (mode == 0) APSS_TRY(launch_probe<0>(h, a, lds));
+    if (wave_path && getenv("APSS_DIAG")) {
+      // diagnostic build: in-kernel cycle stamps per round segment (shares only; never a benchmark number)
+      APSS_TRY(ensure(h, h->dbg, 8));
+      HIPCHK(h, hipMemsetAsync(h->dbg.p, 0, 8 * sizeof(unsigned long long), h->stream));
+      a.dbg = h->dbg.p;
+      auto kern = k_probe_wave<kProbeBlock, 4, true>;
+      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(kProbeBlock), lds, h->stream, a);
+      HIPCHK(h, hipGetLastError());
+      unsigned long long d[8];
+      HIPCHK(h, hipMemcpyAsync(d, h->dbg.p, sizeof(d), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      unsigned long long tot = 0;
+      for (int k = 0; k < 7; ++k) tot += d[k];
+      fprintf(stderr, "[apss diag] stage+flatten %.1f%% | atomics %.1f%% | longs/rest %.1f%% | barrier G %.1f%% | survivors %.1f%% | "
+                      "re-zero %.1f%% | barrier U %.1f%% | cycles/round/wave %.0f\n",
+              100.0 * d[0] / tot, 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot,
+              100.0 * d[5] / tot, 100.0 * d[6] / tot, (double)tot / ((double)a.n_tiles * a.nq * (kProbeBlock / kWave)));
+    } else if (wave_path) {
+      auto kern = k_probe_wave<kProbeBlock, 4>;
+      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(kProbeBlock), lds, h->stream, a);
+      HIPCHK(h, hipGetLastError());
+    } else if (mode == 0) APSS_TRY(launch_probe<0>(h, a, lds));
     else if (mode == 1) APSS_TRY(launch_probe<1>(h, a, lds));
     else APSS_TRY(launch_probe<2>(h, a, lds));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -439,7 +485,8 @@ int32_t query_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_
                        const float *d_val, const int64_t *d_ext, int64_t *n_results) {
   int64_t kept_rows = 0, kept_nnz = 0;
   APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, false, &kept_rows, &kept_nnz));
-  return probe(h, kept_rows, h->q_rowptr.p, h->q_idx.p, h->q_val.p, h->q_ext.p, h->q_sub.p, -1, n_results);
+  return probe(h, kept_rows, h->q_rowptr.p, h->q_idx.p, h->q_val.p, h->q_ext.p, h->q_sub.p, -1, h->q_max_nnz, h->q_max_norm2,
+               kept_nnz, n_results);
 }
 
 }  // namespace
@@ -509,7 +556,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   if (cfg->capacity_nnz > 0) {
     if (ensure(h, h->idx, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
         ensure(h, h->val, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
-        ensure(h, h->post, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK) {
+        ensure(h, h->post, (size_t)cfg->capacity_nnz + 64, 0, true) != APSS_OK) {
       g_create_error = h->err;
       apss_destroy(h);
       return APSS_E_NOMEM;
@@ -528,7 +575,7 @@ void apss_destroy(apss_handle *h) {
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
   release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val);
-  release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword);
+  release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword); release(h->dbg);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -573,7 +620,8 @@ int32_t apss_insert_and_query(apss_handle *h, int64_t n, const int64_t *rowptr, 
 
 int32_t apss_self_join(apss_handle *h, int64_t *n_results) {
   APSS_TRY(enter(h));
-  return probe(h, h->n_rows, h->rowptr.p, h->idx.p, h->val.p, h->ext.p, h->sub.p, 0, n_results);
+  return probe(h, h->n_rows, h->rowptr.p, h->idx.p, h->val.p, h->ext.p, h->sub.p, 0, h->store_max_nnz, h->store_max_norm2, h->nnz,
+               n_results);
 }
 
 int32_t apss_result_count(const apss_handle *h, int64_t *n_results) {
@@ -661,7 +709,7 @@ int32_t apss_insert_and_query_dev(apss_handle *h, int64_t n, int64_t nnz, const 
   const int64_t nq = h->n_rows - first;
   // the batch is now rows [first, n_rows) of the store: query it in place (rowptr offsets are absolute)
   return probe(h, nq, h->rowptr.p + first, h->idx.p, h->val.p, h->ext.p + first, h->sharded ? h->sub.p + first : nullptr,
-               first, n_results);
+               first, h->store_max_nnz, h->store_max_norm2, h->nnz, n_results);
 }
 
 int32_t apss_clear(apss_handle *h) {
@@ -672,6 +720,8 @@ int32_t apss_clear(apss_handle *h) {
   h->n_tiles = 0;
   h->n_res = -1;
   h->nonneg = true;
+  h->store_max_nnz = 0;
+  h->store_max_norm2 = 0.f;
   return APSS_OK;
 }
 

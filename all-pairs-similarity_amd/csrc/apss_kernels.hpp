@@ -64,7 +64,7 @@ struct IngestArgs {
   int64_t *row_cnt;   // [n] kept entries (0 for dropped rows)
   float *row_inv;     // [n] 1/norm (1 when not normalising)
   float *row_sub;     // [n] L2 norm of the kept entries (the shard's sub-norm)
-  unsigned int *flags_out;  // bit0 malformed indices, bit1 non-finite value, bit2 negative value kept
+  unsigned int *flags_out;  // [0]: bit0 malformed indices, bit1 non-finite value, bit2 negative value kept; [1]: max kept row length; [2]: bits of the max squared row norm
 };
 
 // one 16-lane group per row
@@ -112,6 +112,10 @@ __global__ void k_ingest_count(IngestArgs a) {
     a.row_inv[row] = inv;
     a.row_sub[row] = sqrtf(sub);
     if (bad) atomicOr(a.flags_out, bad);
+    if (admit) {
+      atomicMax(a.flags_out + 1, (unsigned)cnt);         // longest kept row: picks the probe kernel
+      atomicMax(a.flags_out + 2, __float_as_uint(sub));  // largest squared L2 norm of a kept row (fixed-point range)
+    }
   }
 }
 
@@ -302,17 +306,21 @@ struct ProbeArgs {
   const float *q_val;
   const int64_t *q_ext;
   const float *q_scale;     // shard sub-norm per query row (null: 1)
+  int64_t q_nnz_end;        // q_idx / q_val hold at least this many elements (> 0 when a probe is launched)
   int32_t nq;
   int32_t q_chunk;          // queries per workgroup
   int32_t n_chunks;
   int64_t q_slot_base;      // slot of query row 0 when the batch is stored in the index, else -1
   float theta;
+  float fx_scale;     // fixed-point accumulators: 1.0 is this many units (2^30 or 2^28), k_probe_wave
+  uint32_t theta_fx;  // ceil(theta * fx_scale), computed in double on the host
   // output
   int32_t *res_q;
   int32_t *res_c;
   float *res_s;
   uint64_t res_cap;
   unsigned long long *counters;  // [kCtrCount]
+  unsigned long long *dbg;       // diagnostic build only: per-segment cycle sums [8]
 };
 
 // dynamic-LDS carve (all offsets multiples of 16 B)
@@ -627,6 +635,340 @@ __global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
   if (tid == 0) {
     atomicAdd(&a.counters[kCtrVisits], stat[0]);
     atomicAdd(&a.counters[kCtrCands], stat[1] - stat[2]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_probe_wave: the speed path of the probe for the common regime (non-negative weights, theta > 0, at most
+// BLOCK terms per query).  Differences from k_probe:
+//   * no shared work-item list: term k of the query belongs to wave k % NW; a wave flattens the posting
+//     segments of its own terms with a wave prefix sum and walks them 64 postings per step, so no workgroup
+//     barrier sits between finding the segments and loading them;
+//   * the posting loads of round r+1 are issued at the top of round r (segment look-ups two rounds ahead,
+//     term ids three, row extents four), so a round never waits on a dependent global-load chain;
+//   * accumulators are re-zeroed by writing 0 to exactly the slots the round touched (their postings are
+//     still in registers) instead of clearing the whole tile: LDS traffic proportional to posting visits;
+//     rounds that overflow the register window or sweep a long segment fall back to clearing the tile.
+constexpr int kLongCapW = 1024;  // long segments per round (<= terms per query)
+constexpr int kLongLenW = 256;   // longer segments are swept by the whole workgroup
+
+__host__ __device__ inline size_t probe_wave_lds_bytes(int cb) {
+  return ((size_t)(cb + kWave) * 4 + 2 * (size_t)kLongCapW * 8 + 2 * (size_t)kLongCapW * 4 + (size_t)kSurvCap * 4 + 128 + 15) / 16 * 16;
+}
+
+template <int BLOCK, int U, bool DIAG = false>
+__global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
+  constexpr int NW = BLOCK / kWave;
+  static_assert(BLOCK <= kLongCapW, "one long-list entry per term");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // [cb] u32 fixed-point accumulators + [64] per-lane dummy slots.  Fixed point because LDS float atomics are
+  // serialised on gfx950 (ds_add_f32: ~193 cycles per wave-instruction, 0.33 lanes/clk/CU) while integer LDS
+  // atomics run at ~8 lanes/clk/CU with random addresses (profiles/microbench/lds_atomics.hip).  Every product
+  // is rounded once to a multiple of 1/fx_scale, sums are exact: |error| <= terms * 2^-31 at scale 2^30.
+  uint32_t *acc = (uint32_t *)smem_raw;
+  uint2 *longs = (uint2 *)(acc + a.cb + kWave);           // [2][kLongCapW]
+  float *long_w = (float *)(longs + 2 * kLongCapW);       // [2][kLongCapW]
+  uint32_t *surv = (uint32_t *)(long_w + 2 * kLongCapW);  // [kSurvCap]
+  uint32_t *ctr = surv + kSurvCap;  // per parity p: ctr[4p] long segments, ctr[4p+1] "clear whole tile", ctr[4p+2] survivors
+  unsigned long long *stat = reinterpret_cast<unsigned long long *>(ctr + 8);
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
+  const int cb = a.cb;
+  const int tile = blockIdx.x / a.n_chunks;
+  const int chunk = blockIdx.x % a.n_chunks;
+  const int q0 = chunk * a.q_chunk;
+  const int q1 = min(a.nq, q0 + a.q_chunk);
+  const uint32_t *tp = a.tile_ptr + (int64_t)tile * a.tp_stride;
+  const int64_t tile_row0 = (int64_t)tile * cb;
+  const Posting *post = a.post + a.store_rowptr[tile_row0];
+  const float tile_scale = a.tile_scale ? a.tile_scale[tile] : 1.0f;
+  const int kterm = ln * NW + wv;  // the term of the query this lane looks after
+  const uint32_t dummy = (uint32_t)(cb + ln);  // where an idle lane's 0.0 add lands (conflict-free, stays 0)
+
+  for (int i = tid * 4; i < cb + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < 8) ctr[tid] = 0;
+  const float fxs = a.fx_scale, fxinv = 1.0f / a.fx_scale;
+  unsigned long long my_visits = 0, my_cands = 0;
+
+  // ---- pipeline stages (all loads unconditional with clamped addresses so the compiler can count them) ----
+  struct RowExt { int64_t qb; int nnz; };
+  struct TermW { int32_t term; float w; bool valid; };
+  struct Seg { uint32_t s, len; float w; };
+  struct WaveWork {
+    uint32_t s, len;  // per lane: its term's segment (len 0 when the segment went to the long list)
+    float w;          // per lane: query weight of its term
+    int tot;          // wave-uniform: postings of this wave this round
+    int tw;           // wave-uniform: terms of this wave this round
+    Posting pc[U];    // prefetched postings, step u covers flat positions u*64 + lane
+    float wq[U];      // query weight of that posting's term, pre-multiplied by fx_scale
+    uint32_t act;     // bit u: step u holds a real posting in this lane
+  };
+  auto load_R = [&](int q) {
+    RowExt r;
+    const int qq = min(q, a.nq - 1);
+    r.qb = a.q_rowptr[qq];
+    const int64_t qe = a.q_rowptr[qq + 1];
+    r.nnz = q < q1 ? (int)(qe - r.qb) : 0;
+    return r;
+  };
+  auto load_I = [&](const RowExt &r) {
+    TermW t;
+    t.valid = kterm < r.nnz;
+    int64_t ii = r.qb + (t.valid ? kterm : 0);
+    ii = ii < a.q_nnz_end ? ii : a.q_nnz_end - 1;  // an empty last row starts one past the end
+    t.term = a.q_idx[ii];
+    t.w = a.q_val[ii];
+    return t;
+  };
+  auto load_P = [&](const TermW &t) {
+    Seg g;
+    const uint32_t b = tp[t.term], e = tp[t.term + 1];
+    g.s = b;
+    g.len = t.valid ? e - b : 0u;
+    g.w = t.w;
+    return g;
+  };
+  // Flatten the wave's segments: flat position f of the wave (0 <= f < tot) is posting (f - excl_m) of the
+  // segment m with excl_m <= f < excl_m + len_m.  The segment descriptors sit in lanes 0..tw-1; they are walked
+  // with v_readlane into scalar registers (no LDS round trips), each step fixing up the lanes that lie beyond it.
+  auto flatten = [&](const Seg &g, const RowExt &r, int parity) {
+    WaveWork f;
+    uint32_t len = g.len;
+    my_visits += len;
+    if (len > (uint32_t)kLongLenW) {  // swept by the whole workgroup in its own round
+      const uint32_t k = atomicAdd(&ctr[4 * parity], 1u);
+      longs[parity * kLongCapW + k] = make_uint2(g.s, len);
+      long_w[parity * kLongCapW + k] = g.w;
+      len = 0;
+    }
+    f.s = g.s;
+    f.len = len;
+    f.w = g.w;
+    f.tw = wv < r.nnz ? (r.nnz - wv + NW - 1) / NW : 0;
+    uint32_t base[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      base[u] = 0;
+      f.wq[u] = 0.f;
+    }
+    uint32_t run = 0;
+    for (int m = 0; m < f.tw; ++m) {
+      const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)len, m);
+      if (lm == 0) continue;
+      const uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)g.s, m) - run;
+      const float wm = fxs * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), m));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool sel = (uint32_t)(u * kWave + ln) >= run;
+        base[u] = sel ? bm : base[u];
+        f.wq[u] = sel ? wm : f.wq[u];
+      }
+      run += lm;
+    }
+    f.tot = (int)run;
+    f.act = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t fpos = (uint32_t)(u * kWave + ln);
+      const bool on = fpos < run;
+      f.pc[u] = post[on ? base[u] + fpos : 0u];
+      if (on) f.act |= 1u << u;
+    }
+    return f;
+  };
+
+  RowExt R1 = load_R(q0 + 1), R2 = load_R(q0 + 2), R3 = load_R(q0 + 3);
+  TermW I2, I3;
+  Seg P1, P2;
+  WaveWork wf;
+  {
+    const RowExt R0 = load_R(q0);
+    const TermW I0 = load_I(R0), I1 = load_I(R1);
+    I2 = load_I(R2);
+    const Seg P0 = load_P(I0);
+    P1 = load_P(I1);
+    __syncthreads();  // ctr zeroed before the first long-segment pushes
+    wf = flatten(P0, R0, 0);
+  }
+  __syncthreads();  // accumulators cleared, round-0 long list complete
+
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define APSS_STAMP(k)                                   \
+  if (DIAG) {                                           \
+    const unsigned long long t_ = clock64();            \
+    tsum[k] += t_ - tprev;                              \
+    tprev = t_;                                         \
+  }
+  for (int q = q0; q < q1; ++q) {
+    unsigned long long tprev = DIAG ? clock64() : 0;
+    const int par = (q - q0) & 1;
+    const float qs = a.q_scale ? a.q_scale[q] : 1.0f;
+    const float thr = a.theta * qs * tile_scale;
+    // shard mode: the candidate test is a necessary condition that is verified exactly later, so round it down
+    const uint32_t thr_fx = (a.q_scale || a.tile_scale) ? (uint32_t)(thr * fxs * 0.999999f) : a.theta_fx;
+    const int64_t sl64 = a.q_slot_base >= 0 ? a.q_slot_base + q - tile_row0 : -1;
+    const uint32_t self_local = (sl64 >= 0 && sl64 < cb) ? (uint32_t)sl64 : 0xffffffffu;
+
+    // ---- stage loads for the rounds ahead ----
+    const RowExt R4 = load_R(q + 4);
+    I3 = load_I(R3);
+    P2 = load_P(I2);
+    WaveWork wfn = flatten(P1, R1, par ^ 1);
+    APSS_STAMP(0)
+
+    // ---- accumulate round q ----
+    auto check = [&](const uint32_t slot, const uint32_t p, const uint32_t old) {
+      my_cands += (old == 0u && slot != self_local) ? 1u : 0u;
+      if (old < thr_fx && old + p >= thr_fx) {  // this add took the candidate across the threshold
+        const uint32_t k = atomicAdd(&ctr[4 * par + 2], 1u);
+        if (k < (uint32_t)kSurvCap) surv[k] = slot;
+      }
+    };
+    auto visit = [&](const Posting pc, const float wqs) {
+      const uint32_t p = __float2uint_rn(wqs * pc.w);
+      check(pc.slot, p, atomicAdd(&acc[pc.slot], p));
+    };
+    uint32_t sl[U];
+    {
+      // the register window: all LDS atomics issued back to back, one wait, then the threshold checks
+      uint32_t p[U], old[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool on = (wf.act >> u) & 1u;
+        sl[u] = on ? wf.pc[u].slot : dummy;
+        p[u] = on ? __float2uint_rn(wf.wq[u] * wf.pc[u].w) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) old[u] = atomicAdd(&acc[sl[u]], p[u]);  // ds_add_rtn_u32
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((wf.act >> u) & 1u) check(sl[u], p[u], old[u]);
+    }
+    APSS_STAMP(1)
+    if (wf.tot > U * kWave) {  // wave-uniform: more postings than the register window holds
+      if (ln == 0) ctr[4 * par + 1] = 1;
+      for (int f0 = U * kWave; f0 < wf.tot; f0 += kWave) {
+        const uint32_t fpos = (uint32_t)(f0 + ln);
+        uint32_t bs = 0, run = 0;
+        float wq_ = 0.f;
+        for (int m = 0; m < wf.tw; ++m) {
+          const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)wf.len, m);
+          const uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)wf.s, m) - run;
+          const float wm = fxs * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wf.w), m));
+          const bool sel = lm != 0 && fpos >= run;
+          bs = sel ? bm : bs;
+          wq_ = sel ? wm : wq_;
+          run += lm;
+        }
+        if (fpos < (uint32_t)wf.tot) visit(post[bs + fpos], wq_);
+      }
+    }
+    const uint32_t n_long = ctr[4 * par];
+    for (uint32_t j = 0; j < n_long; ++j) {
+      const uint2 sgm = longs[par * kLongCapW + j];
+      const float wq_ = fxs * long_w[par * kLongCapW + j];
+      uint32_t k = tid;
+      for (; k + 3 * BLOCK < sgm.y; k += 4 * BLOCK) {  // four loads in flight per lane
+        const Posting p0 = post[sgm.x + k], p1 = post[sgm.x + k + BLOCK], p2 = post[sgm.x + k + 2 * BLOCK],
+                      p3 = post[sgm.x + k + 3 * BLOCK];
+        visit(p0, wq_);
+        visit(p1, wq_);
+        visit(p2, wq_);
+        visit(p3, wq_);
+      }
+      for (; k < sgm.y; k += BLOCK) visit(post[sgm.x + k], wq_);
+    }
+    APSS_STAMP(2)
+    __syncthreads();  // every add of round q has landed
+    APSS_STAMP(3)
+
+    // ---- threshold prune + compaction (IWA:93-95) ----
+    const uint2 fl = *reinterpret_cast<const uint2 *>(&ctr[4 * par + 1]);  // {clear-whole-tile flag, survivors}
+    const uint32_t n_surv = fl.y;
+    const bool full_zero = n_long > 0 || fl.x != 0 || n_surv > (uint32_t)kSurvCap;
+    if (n_surv > 0) {
+      const int64_t qext = a.q_ext[q];
+      if (n_surv <= (uint32_t)kSurvCap) {
+        for (uint32_t i = tid; i < (n_surv + kWave - 1) / kWave * kWave; i += BLOCK) {
+          bool ok = false;
+          uint32_t c = 0;
+          float sc = 0.f;
+          if (i < n_surv) {
+            c = surv[i];
+            sc = (float)acc[c] * fxinv;
+            const int64_t gs = tile_row0 + c;
+            ok = a.ext_id[gs] != qext && (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs] * 0.999999f);
+          }
+          const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+          if (ok && o < a.res_cap) {
+            a.res_q[o] = q;
+            a.res_c[o] = (int32_t)(tile_row0 + c);
+            a.res_s[o] = sc;
+          }
+        }
+      } else {
+        for (int i = tid; i < (cb + BLOCK - 1) / BLOCK * BLOCK; i += BLOCK) {
+          bool ok = false;
+          float sc = 0.f;
+          if (i < cb) {
+            const uint32_t raw = acc[i];
+            sc = (float)raw * fxinv;
+            const int64_t gs = tile_row0 + i;
+            ok = raw >= thr_fx && gs < a.n_rows && a.ext_id[gs] != qext &&
+                 (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs] * 0.999999f);
+          }
+          const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+          if (ok && o < a.res_cap) {
+            a.res_q[o] = q;
+            a.res_c[o] = (int32_t)(tile_row0 + i);
+            a.res_s[o] = sc;
+          }
+        }
+      }
+      __syncthreads();  // final scores read before they are cleared
+    }
+
+    APSS_STAMP(4)
+    // ---- re-zero what the round touched ----
+    if (full_zero) {
+      for (int i = tid * 4; i < cb; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[sl[u]] = 0u;
+    }
+    APSS_STAMP(5)
+    if (tid == 0) {
+      // this parity's long list was consumed before the barrier above and is refilled during round q+1;
+      // the OTHER parity's flags were last read before the closing barrier of round q-1 and are next
+      // written after the closing barrier of this round, so they can be cleared here without a race
+      ctr[4 * par] = 0;
+      ctr[4 * (par ^ 1) + 1] = 0;
+      ctr[4 * (par ^ 1) + 2] = 0;
+    }
+    __syncthreads();  // clears done before any add of round q+1
+    APSS_STAMP(6)
+
+    wf = wfn;
+    P1 = P2;
+    I2 = I3;
+    R1 = R2;
+    R2 = R3;
+    R3 = R4;
+  }
+
+#undef APSS_STAMP
+  if (DIAG && ln == 0 && a.dbg)
+    for (int k = 0; k < 8; ++k) atomicAdd(&a.dbg[k], tsum[k]);
+  __syncthreads();
+  if (tid < 3) stat[tid] = 0;
+  __syncthreads();
+  atomicAdd(&stat[0], my_visits);
+  atomicAdd(&stat[1], my_cands);
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&a.counters[kCtrVisits], stat[0]);
+    atomicAdd(&a.counters[kCtrCands], stat[1]);
   }
 }
 

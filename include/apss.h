@@ -48,6 +48,7 @@ extern "C" {
                                     max-weight == 1.0 per EntryProxyActor.scala:51-57) */
 #define APSS_FLAG_NORMALIZE 4u   /* L2-normalise rows on ingest (benchmark/LoadGenerator.scala:34-37) */
 #define APSS_FLAG_FORCE_SCAN 8u  /* always use the general accumulator-scan kernel (signed weights path) */
+#define APSS_FLAG_FORCE_GENERAL 16u /* never use the per-wave speed path of the probe (test hook) */
 
 typedef struct apss_handle apss_handle;
 

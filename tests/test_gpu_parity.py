@@ -51,10 +51,14 @@ def test_kat_section33_through_abi(apss_mod):
 
 @pytest.mark.parametrize("name", ["mini_uniform_t03", "mini_zipf_t05", "mini_zipf_t08"])
 @pytest.mark.parametrize("tile_rows", [256, 1024, 0])
-def test_golden_fixture(apss_mod, name, tile_rows):
+@pytest.mark.parametrize("general", [False, True])
+def test_golden_fixture(apss_mod, name, tile_rows, general):
+    """both probe kernels: the per-wave speed path and the general item-list kernel"""
+    from apss import _lib
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     dim, theta = int(z["dim"]), float(z["theta"])
-    got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=tile_rows)
+    got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=tile_rows,
+                        flags=_lib.FLAG_FORCE_GENERAL if general else 0)
     want = to_map(z["out_q"], z["out_c"], z["out_sim"])
     assert_same_pairs(got, want, theta)
     # top-k (first k by (-score, q, c)): equal sets imply equal top-k up to score ties inside 1e-5
@@ -64,14 +68,15 @@ def test_golden_fixture(apss_mod, name, tile_rows):
     assert st["posting_visits"] == int(visits)
 
 
-@pytest.mark.parametrize("flags_name", ["fast", "force_scan"])
+@pytest.mark.parametrize("flags_name", ["fast", "force_general", "force_scan"])
 def test_scan_path_equals_crossing_path(apss_mod, oracle, flags_name):
     from apss import _lib
     n, dim, nnz, theta = 1500, 300, 12, 0.45
     rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=21, dup_frac=0.1)
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
     got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=512,
-                        flags=_lib.FLAG_FORCE_SCAN if flags_name == "force_scan" else 0)
+                        flags={"fast": 0, "force_general": _lib.FLAG_FORCE_GENERAL,
+                               "force_scan": _lib.FLAG_FORCE_SCAN}[flags_name])
     assert len(want) > 100
     assert_same_pairs(got, want, theta)
     # candidate pairs scored == distinct (q, c != q) sharing a term
@@ -211,8 +216,9 @@ def test_c2_shape_reduced(apss_mod, oracle):
     rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=synth.CONFIGS["c2"]["seed"])
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
     assert len(want) > 500
-    for tr in (0, 8192):
-        got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=tr)
+    from apss import _lib
+    for tr, fl in ((0, 0), (8192, 0), (0, _lib.FLAG_FORCE_GENERAL)):
+        got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=tr, flags=fl)
         assert_same_pairs(got, want, theta)
         assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
 
