@@ -350,15 +350,46 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.q_slot_base = q_slot_base;
   a.theta = (float)theta;
   a.counters = h->counters.p;
-  // speed path: per-wave flattened segments + prefetch + touched-slot re-zeroing (k_probe_wave)
-  // Fixed-point accumulators need every partial score to fit: by Cauchy-Schwarz a partial sum of non-negative
-  // products is at most |q| * |c| <= the product of the largest row norms.
+  // speed path (k_probe_wave): fixed-point accumulators need every partial score to fit: by Cauchy-Schwarz a
+  // partial sum of non-negative products is at most |q| * |c| <= the product of the largest row norms.
   const double bound = std::sqrt((double)q_max_norm2) * std::sqrt((double)h->store_max_norm2) * 1.0001 + 1e-6;
   const double fx_scale = bound < 3.9 ? 1073741824.0 : (bound < 15.6 ? 268435456.0 : 0.0);
-  const bool wave_path = mode == 0 && fx_scale > 0 && q_max_nnz <= kProbeBlock && !(h->cfg.flags & APSS_FLAG_FORCE_GENERAL);
+  // kernel shapes: A = 8 waves x 64-chunk window, one workgroup per CU at 32768-row tiles; C = 8 waves x 40-chunk
+  // window, sized so that TWO workgroups share a CU at 16384-row tiles (their barriers and LDS bursts interleave)
+  const char *var_env = getenv("APSS_WAVE_VARIANT");  // test / A-B hook: A, B, C or D
+  char variant = var_env ? var_env[0] : (h->cb <= 16384 ? 'C' : 'A');
+  if (variant != 'A' && variant != 'B' && variant != 'C' && variant != 'D') variant = 'A';
+  const int wave_block = variant == 'B' ? 1024 : (variant == 'D' ? 256 : 512);
+  const int wave_u = (variant == 'A' || variant == 'D') ? 8 : 5;
+  const int wave_longcap = (variant == 'A' || variant == 'B') ? 256 : 128;
+  const int wave_survcap = (variant == 'A' || variant == 'B') ? 1024 : 512;
+  const bool wave_path = mode == 0 && fx_scale > 0 && q_max_nnz <= wave_block && !(h->cfg.flags & APSS_FLAG_FORCE_GENERAL);
   a.fx_scale = (float)fx_scale;
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::ceil(theta * fx_scale));
-  const size_t lds = wave_path ? probe_wave_lds_bytes(h->cb) : probe_lds_bytes(h->cb, kProbeBlock, mode);
+  const size_t lds = wave_path ? probe_wave_lds_bytes(h->cb, wave_block, wave_u, wave_longcap, wave_survcap)
+                               : probe_lds_bytes(h->cb, kProbeBlock, mode);
+  auto launch_wave = [&](bool diag) -> int32_t {
+    const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
+#define APSS_LAUNCH_WAVE(B, UU, LC, SC)                                                                                  \
+    do {                                                                                                                   \
+      if (diag) {                                                                                                          \
+        auto kern = k_probe_wave<B, UU, LC, SC, true>;                                                                     \
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(B), lds, h->stream, a);                                                        \
+      } else {                                                                                                             \
+        auto kern = k_probe_wave<B, UU, LC, SC, false>;                                                                    \
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(B), lds, h->stream, a);                                                        \
+      }                                                                                                                    \
+    } while (0)
+    if (variant == 'A') APSS_LAUNCH_WAVE(512, 8, 256, 1024);
+    else if (variant == 'B') APSS_LAUNCH_WAVE(1024, 5, 256, 1024);
+    else if (variant == 'C') APSS_LAUNCH_WAVE(512, 5, 128, 512);
+    else APSS_LAUNCH_WAVE(256, 8, 128, 512);
+#undef APSS_LAUNCH_WAVE
+    HIPCHK(h, hipGetLastError());
+    return APSS_OK;
+  };
 
   if (h->res_q.cap == 0) {
     const size_t cap0 = 1u << 20;
@@ -379,10 +410,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       APSS_TRY(ensure(h, h->dbg, 8));
       HIPCHK(h, hipMemsetAsync(h->dbg.p, 0, 8 * sizeof(unsigned long long), h->stream));
       a.dbg = h->dbg.p;
-      auto kern = k_probe_wave<kProbeBlock, 4, true>;
-      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(kProbeBlock), lds, h->stream, a);
-      HIPCHK(h, hipGetLastError());
+      APSS_TRY(launch_wave(true));
       unsigned long long d[8];
       HIPCHK(h, hipMemcpyAsync(d, h->dbg.p, sizeof(d), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -391,12 +419,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       fprintf(stderr, "[apss diag] stage+flatten %.1f%% | atomics %.1f%% | longs/rest %.1f%% | barrier G %.1f%% | survivors %.1f%% | "
                       "re-zero %.1f%% | barrier U %.1f%% | cycles/round/wave %.0f\n",
               100.0 * d[0] / tot, 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot,
-              100.0 * d[5] / tot, 100.0 * d[6] / tot, (double)tot / ((double)a.n_tiles * a.nq * (kProbeBlock / kWave)));
+              100.0 * d[5] / tot, 100.0 * d[6] / tot, (double)tot / ((double)a.n_tiles * a.nq * (wave_block / kWave)));
     } else if (wave_path) {
-      auto kern = k_probe_wave<kProbeBlock, 4>;
-      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(kProbeBlock), lds, h->stream, a);
-      HIPCHK(h, hipGetLastError());
+      APSS_TRY(launch_wave(false));
     } else if (mode == 0) APSS_TRY(launch_probe<0>(h, a, lds));
     else if (mode == 1) APSS_TRY(launch_probe<1>(h, a, lds));
     else APSS_TRY(launch_probe<2>(h, a, lds));

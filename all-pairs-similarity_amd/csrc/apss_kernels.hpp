@@ -640,36 +640,55 @@ __global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // k_probe_wave: the speed path of the probe for the common regime (non-negative weights, theta > 0, at most
-// BLOCK terms per query).  Differences from k_probe:
-//   * no shared work-item list: term k of the query belongs to wave k % NW; a wave flattens the posting
-//     segments of its own terms with a wave prefix sum and walks them 64 postings per step, so no workgroup
-//     barrier sits between finding the segments and loading them;
-//   * the posting loads of round r+1 are issued at the top of round r (segment look-ups two rounds ahead,
-//     term ids three, row extents four), so a round never waits on a dependent global-load chain;
+// BLOCK terms per query, scores bounded so that u32 fixed point holds them).  Differences from k_probe:
+//   * u32 fixed-point accumulators: LDS float atomics are serialised on gfx950 (ds_add_f32: ~193 cycles per
+//     wave-instruction = 0.33 lanes/clk/CU) while integer LDS atomics run at ~8 lanes/clk/CU with random
+//     addresses (profiles/microbench/lds_atomics.hip).  Every product is rounded once to a multiple of
+//     1/fx_scale and sums are exact: |error| <= terms * 2^-31 at scale 2^30 (better than an fp32 running sum);
+//   * no workgroup-wide work list: term k of the query belongs to wave k % NW, lane k / NW.  A wave cuts its own
+//     segments into 8-posting chunks (64 B), numbers them with a DPP prefix sum and keeps the chunk descriptors
+//     in a wave-private LDS strip, so no workgroup barrier sits between finding segments and loading them;
+//   * deep prefetch: the postings of round r+2 are requested at the top of round r (segment look-ups for r+3,
+//     term ids for r+4, row extents for r+5), every load unconditional so the waits can be counted;
 //   * accumulators are re-zeroed by writing 0 to exactly the slots the round touched (their postings are
-//     still in registers) instead of clearing the whole tile: LDS traffic proportional to posting visits;
-//     rounds that overflow the register window or sweep a long segment fall back to clearing the tile.
-constexpr int kLongCapW = 1024;  // long segments per round (<= terms per query)
+//     still in registers): LDS traffic proportional to posting visits, not to the tile size.  Rounds that
+//     overflow the register window or sweep a long segment fall back to clearing the tile.
+constexpr int kChunk = 8;        // postings per chunk: 8 lanes x 8 B = 64 B
 constexpr int kLongLenW = 256;   // longer segments are swept by the whole workgroup
 
-__host__ __device__ inline size_t probe_wave_lds_bytes(int cb) {
-  return ((size_t)(cb + kWave) * 4 + 2 * (size_t)kLongCapW * 8 + 2 * (size_t)kLongCapW * 4 + (size_t)kSurvCap * 4 + 128 + 15) / 16 * 16;
+__host__ __device__ inline size_t probe_wave_lds_bytes(int cb, int block, int u, int longcap, int survcap) {
+  return ((size_t)(cb + kWave) * 4 + (size_t)(block / kWave) * (kWave / kChunk) * u * 16 + 3 * (size_t)longcap * 12 +
+          (size_t)survcap * 4 + 128 + 15) / 16 * 16;
 }
 
-template <int BLOCK, int U, bool DIAG = false>
+// inclusive prefix sum over the 64 lanes with DPP (VALU only, no LDS round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+  return x;
+}
+
+// LONGCAP: long segments per round kept in the workgroup list (more stay with their wave); SURVCAP: threshold
+// crossings per round kept in LDS (more: the round falls back to scanning the accumulators)
+template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool DIAG = false>
 __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
-  static_assert(BLOCK <= kLongCapW, "one long-list entry per term");
+  constexpr int kLongCapW = LONGCAP;
+  constexpr int GPW = kWave / kChunk;  // chunk groups per wave step (8)
+  constexpr int WIN = GPW * U;         // chunks in one wave's register window
+  static_assert(WIN <= kWave, "the window strip is cleared by one store per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // [cb] u32 fixed-point accumulators + [64] per-lane dummy slots.  Fixed point because LDS float atomics are
-  // serialised on gfx950 (ds_add_f32: ~193 cycles per wave-instruction, 0.33 lanes/clk/CU) while integer LDS
-  // atomics run at ~8 lanes/clk/CU with random addresses (profiles/microbench/lds_atomics.hip).  Every product
-  // is rounded once to a multiple of 1/fx_scale, sums are exact: |error| <= terms * 2^-31 at scale 2^30.
-  uint32_t *acc = (uint32_t *)smem_raw;
-  uint2 *longs = (uint2 *)(acc + a.cb + kWave);           // [2][kLongCapW]
-  float *long_w = (float *)(longs + 2 * kLongCapW);       // [2][kLongCapW]
-  uint32_t *surv = (uint32_t *)(long_w + 2 * kLongCapW);  // [kSurvCap]
-  uint32_t *ctr = surv + kSurvCap;  // per parity p: ctr[4p] long segments, ctr[4p+1] "clear whole tile", ctr[4p+2] survivors
+  uint32_t *acc = (uint32_t *)smem_raw;                    // [cb] accumulators + [64] per-lane dummy slots
+  uint4 *items = (uint4 *)(acc + a.cb + kWave);            // [NW][WIN] {first posting, count, weight bits, -}
+  uint2 *longs = (uint2 *)(items + NW * WIN);              // [3][kLongCapW]
+  float *long_w = (float *)(longs + 3 * kLongCapW);        // [3][kLongCapW]
+  uint32_t *surv = (uint32_t *)(long_w + 3 * kLongCapW);   // [SURVCAP]
+  // ctr[0..2] long segments of round (r % 3); ctr[4 + 2p] "clear whole tile", ctr[5 + 2p] survivors (p = r & 1)
+  uint32_t *ctr = surv + SURVCAP;
   unsigned long long *stat = reinterpret_cast<unsigned long long *>(ctr + 8);
 
   const int tid = threadIdx.x;
@@ -683,12 +702,14 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   const int64_t tile_row0 = (int64_t)tile * cb;
   const Posting *post = a.post + a.store_rowptr[tile_row0];
   const float tile_scale = a.tile_scale ? a.tile_scale[tile] : 1.0f;
-  const int kterm = ln * NW + wv;  // the term of the query this lane looks after
-  const uint32_t dummy = (uint32_t)(cb + ln);  // where an idle lane's 0.0 add lands (conflict-free, stays 0)
+  const int kterm = ln * NW + wv;              // the term of the query this lane looks after
+  const uint32_t dummy = (uint32_t)(cb + ln);  // where an idle lane's +0 lands (conflict-free, stays 0)
+  const uint32_t lo = (uint32_t)(ln % kChunk); // posting of the chunk this lane handles
+  uint4 *wl = items + wv * WIN;                // this wave's chunk strip
+  const float fxs = a.fx_scale, fxinv = 1.0f / a.fx_scale;
 
   for (int i = tid * 4; i < cb + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
-  if (tid < 8) ctr[tid] = 0;
-  const float fxs = a.fx_scale, fxinv = 1.0f / a.fx_scale;
+  if (tid < 16) ctr[tid] = 0;
   unsigned long long my_visits = 0, my_cands = 0;
 
   // ---- pipeline stages (all loads unconditional with clamped addresses so the compiler can count them) ----
@@ -696,13 +717,13 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   struct TermW { int32_t term; float w; bool valid; };
   struct Seg { uint32_t s, len; float w; };
   struct WaveWork {
-    uint32_t s, len;  // per lane: its term's segment (len 0 when the segment went to the long list)
-    float w;          // per lane: query weight of its term
-    int tot;          // wave-uniform: postings of this wave this round
-    int tw;           // wave-uniform: terms of this wave this round
-    Posting pc[U];    // prefetched postings, step u covers flat positions u*64 + lane
-    float wq[U];      // query weight of that posting's term, pre-multiplied by fx_scale
-    uint32_t act;     // bit u: step u holds a real posting in this lane
+    uint32_t s, len, excl;  // per lane: its term's segment and the number of chunks of the lanes before it
+    float w;                // per lane: query weight of its term
+    int totch;              // wave-uniform: chunks of this wave this round
+    int tw;                 // wave-uniform: terms of this wave this round
+    Posting pc[U];          // prefetched postings: step u, chunk u * GPW + lane / kChunk, posting lane % kChunk
+    float wq[U];            // query weight of that chunk's term, pre-multiplied by fx_scale
+    uint32_t act;           // bit u: step u holds a real posting in this lane
   };
   auto load_R = [&](int q) {
     RowExt r;
@@ -729,69 +750,62 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     g.w = t.w;
     return g;
   };
-  // Flatten the wave's segments: flat position f of the wave (0 <= f < tot) is posting (f - excl_m) of the
-  // segment m with excl_m <= f < excl_m + len_m.  The segment descriptors sit in lanes 0..tw-1; they are walked
-  // with v_readlane into scalar registers (no LDS round trips), each step fixing up the lanes that lie beyond it.
-  auto flatten = [&](const Seg &g, const RowExt &r, int parity) {
+  auto flatten = [&](const Seg &g, const RowExt &r, int li) {
     WaveWork f;
     uint32_t len = g.len;
     my_visits += len;
     if (len > (uint32_t)kLongLenW) {  // swept by the whole workgroup in its own round
-      const uint32_t k = atomicAdd(&ctr[4 * parity], 1u);
-      longs[parity * kLongCapW + k] = make_uint2(g.s, len);
-      long_w[parity * kLongCapW + k] = g.w;
-      len = 0;
+      const uint32_t k = atomicAdd(&ctr[li], 1u);
+      if (k < (uint32_t)kLongCapW) {
+        longs[li * kLongCapW + k] = make_uint2(g.s, len);
+        long_w[li * kLongCapW + k] = g.w;
+        len = 0;
+      }  // else: the list is full, the segment stays with this wave (slow path below)
     }
+    const uint32_t nch = (len + kChunk - 1) / kChunk;
+    const uint32_t incl = wave_incl_scan(nch);
+    const uint32_t excl = incl - nch;
     f.s = g.s;
     f.len = len;
+    f.excl = excl;
     f.w = g.w;
     f.tw = wv < r.nnz ? (r.nnz - wv + NW - 1) / NW : 0;
-    uint32_t base[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      base[u] = 0;
-      f.wq[u] = 0.f;
+    f.totch = __builtin_amdgcn_readlane((int)incl, kWave - 1);
+    // chunk descriptors into the wave's strip: clear it, then every lane adds the chunks of its own segment
+    if (ln < WIN) wl[ln] = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t wbits = __float_as_uint(fxs * g.w);
+    for (uint32_t k = 0;; ++k) {
+      const bool more = k < nch && excl + k < (uint32_t)WIN;
+      if (!__any(more)) break;
+      if (more) wl[excl + k] = make_uint4(g.s + k * kChunk, min((uint32_t)kChunk, len - k * kChunk), wbits, 0u);
     }
-    uint32_t run = 0;
-    for (int m = 0; m < f.tw; ++m) {
-      const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)len, m);
-      if (lm == 0) continue;
-      const uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)g.s, m) - run;
-      const float wm = fxs * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), m));
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool sel = (uint32_t)(u * kWave + ln) >= run;
-        base[u] = sel ? bm : base[u];
-        f.wq[u] = sel ? wm : f.wq[u];
-      }
-      run += lm;
-    }
-    f.tot = (int)run;
+    // (LDS operations of one wave execute in order: the reads below see the stores above)
     f.act = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t fpos = (uint32_t)(u * kWave + ln);
-      const bool on = fpos < run;
-      f.pc[u] = post[on ? base[u] + fpos : 0u];
-      if (on) f.act |= 1u << u;
+      const uint4 it = wl[u * GPW + ln / kChunk];
+      f.wq[u] = __uint_as_float(it.z);
+      f.pc[u] = post[it.x + lo];  // an empty descriptor reads post[lo]: valid memory, masked below
+      if (lo < it.y) f.act |= 1u << u;
     }
     return f;
   };
 
-  RowExt R1 = load_R(q0 + 1), R2 = load_R(q0 + 2), R3 = load_R(q0 + 3);
-  TermW I2, I3;
-  Seg P1, P2;
-  WaveWork wf;
+  RowExt R1 = load_R(q0 + 1), R2 = load_R(q0 + 2), R3 = load_R(q0 + 3), R4 = load_R(q0 + 4);
+  TermW I3, I4;
+  Seg P2, P3;
+  WaveWork wf0, wf1;
   {
     const RowExt R0 = load_R(q0);
-    const TermW I0 = load_I(R0), I1 = load_I(R1);
-    I2 = load_I(R2);
-    const Seg P0 = load_P(I0);
-    P1 = load_P(I1);
-    __syncthreads();  // ctr zeroed before the first long-segment pushes
-    wf = flatten(P0, R0, 0);
+    const TermW I0 = load_I(R0), I1 = load_I(R1), I2 = load_I(R2);
+    I3 = load_I(R3);
+    const Seg P0 = load_P(I0), P1 = load_P(I1);
+    P2 = load_P(I2);
+    __syncthreads();  // counters zeroed before the first long-segment pushes
+    wf0 = flatten(P0, R0, 0);
+    wf1 = flatten(P1, R1, 1);
   }
-  __syncthreads();  // accumulators cleared, round-0 long list complete
+  __syncthreads();  // accumulators cleared, long lists of rounds 0 and 1 complete
 
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define APSS_STAMP(k)                                   \
@@ -800,6 +814,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     tsum[k] += t_ - tprev;                              \
     tprev = t_;                                         \
   }
+  int l3 = 0;  // (q - q0) % 3
   for (int q = q0; q < q1; ++q) {
     unsigned long long tprev = DIAG ? clock64() : 0;
     const int par = (q - q0) & 1;
@@ -811,18 +826,19 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     const uint32_t self_local = (sl64 >= 0 && sl64 < cb) ? (uint32_t)sl64 : 0xffffffffu;
 
     // ---- stage loads for the rounds ahead ----
-    const RowExt R4 = load_R(q + 4);
-    I3 = load_I(R3);
-    P2 = load_P(I2);
-    WaveWork wfn = flatten(P1, R1, par ^ 1);
+    const RowExt R5 = load_R(q + 5);
+    I4 = load_I(R4);
+    P3 = load_P(I3);
+    const int l3n = l3 == 0 ? 2 : l3 - 1;  // (l3 + 2) % 3
+    WaveWork wf2 = flatten(P2, R2, l3n);
     APSS_STAMP(0)
 
     // ---- accumulate round q ----
     auto check = [&](const uint32_t slot, const uint32_t p, const uint32_t old) {
       my_cands += (old == 0u && slot != self_local) ? 1u : 0u;
       if (old < thr_fx && old + p >= thr_fx) {  // this add took the candidate across the threshold
-        const uint32_t k = atomicAdd(&ctr[4 * par + 2], 1u);
-        if (k < (uint32_t)kSurvCap) surv[k] = slot;
+        const uint32_t k = atomicAdd(&ctr[5 + 2 * par], 1u);
+        if (k < (uint32_t)SURVCAP) surv[k] = slot;
       }
     };
     auto visit = [&](const Posting pc, const float wqs) {
@@ -835,39 +851,42 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
       uint32_t p[U], old[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool on = (wf.act >> u) & 1u;
-        sl[u] = on ? wf.pc[u].slot : dummy;
-        p[u] = on ? __float2uint_rn(wf.wq[u] * wf.pc[u].w) : 0u;
+        const bool on = (wf0.act >> u) & 1u;
+        sl[u] = on ? wf0.pc[u].slot : dummy;
+        p[u] = on ? __float2uint_rn(wf0.wq[u] * wf0.pc[u].w) : 0u;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) old[u] = atomicAdd(&acc[sl[u]], p[u]);  // ds_add_rtn_u32
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if ((wf.act >> u) & 1u) check(sl[u], p[u], old[u]);
+        if ((wf0.act >> u) & 1u) check(sl[u], p[u], old[u]);
     }
     APSS_STAMP(1)
-    if (wf.tot > U * kWave) {  // wave-uniform: more postings than the register window holds
-      if (ln == 0) ctr[4 * par + 1] = 1;
-      for (int f0 = U * kWave; f0 < wf.tot; f0 += kWave) {
-        const uint32_t fpos = (uint32_t)(f0 + ln);
-        uint32_t bs = 0, run = 0;
+    if (wf0.totch > WIN) {  // wave-uniform: more chunks than the register window holds
+      if (ln == 0) ctr[4 + 2 * par] = 1;
+      for (int c0 = WIN; c0 < wf0.totch; c0 += GPW) {
+        const uint32_t c = (uint32_t)(c0 + ln / kChunk);
+        uint32_t st = 0, cn = 0;
         float wq_ = 0.f;
-        for (int m = 0; m < wf.tw; ++m) {
-          const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)wf.len, m);
-          const uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)wf.s, m) - run;
-          const float wm = fxs * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wf.w), m));
-          const bool sel = lm != 0 && fpos >= run;
-          bs = sel ? bm : bs;
+        for (int m = 0; m < wf0.tw; ++m) {
+          const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)wf0.excl, m);
+          const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)wf0.len, m);
+          const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)wf0.s, m);
+          const float wm = fxs * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wf0.w), m));
+          const uint32_t nm = (lm + kChunk - 1) / kChunk;
+          const bool sel = c >= em && c < em + nm;
+          const uint32_t k = c - em;
+          st = sel ? sm + k * kChunk : st;
+          cn = sel ? min((uint32_t)kChunk, lm - k * kChunk) : cn;
           wq_ = sel ? wm : wq_;
-          run += lm;
         }
-        if (fpos < (uint32_t)wf.tot) visit(post[bs + fpos], wq_);
+        if (lo < cn) visit(post[st + lo], wq_);
       }
     }
-    const uint32_t n_long = ctr[4 * par];
+    const uint32_t n_long = min(ctr[l3], (uint32_t)kLongCapW);
     for (uint32_t j = 0; j < n_long; ++j) {
-      const uint2 sgm = longs[par * kLongCapW + j];
-      const float wq_ = fxs * long_w[par * kLongCapW + j];
+      const uint2 sgm = longs[l3 * kLongCapW + j];
+      const float wq_ = fxs * long_w[l3 * kLongCapW + j];
       uint32_t k = tid;
       for (; k + 3 * BLOCK < sgm.y; k += 4 * BLOCK) {  // four loads in flight per lane
         const Posting p0 = post[sgm.x + k], p1 = post[sgm.x + k + BLOCK], p2 = post[sgm.x + k + 2 * BLOCK],
@@ -884,12 +903,12 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     APSS_STAMP(3)
 
     // ---- threshold prune + compaction (IWA:93-95) ----
-    const uint2 fl = *reinterpret_cast<const uint2 *>(&ctr[4 * par + 1]);  // {clear-whole-tile flag, survivors}
+    const uint2 fl = *reinterpret_cast<const uint2 *>(&ctr[4 + 2 * par]);  // {clear-whole-tile flag, survivors}
     const uint32_t n_surv = fl.y;
-    const bool full_zero = n_long > 0 || fl.x != 0 || n_surv > (uint32_t)kSurvCap;
+    const bool full_zero = n_long > 0 || fl.x != 0 || n_surv > (uint32_t)SURVCAP;
     if (n_surv > 0) {
       const int64_t qext = a.q_ext[q];
-      if (n_surv <= (uint32_t)kSurvCap) {
+      if (n_surv <= (uint32_t)SURVCAP) {
         for (uint32_t i = tid; i < (n_surv + kWave - 1) / kWave * kWave; i += BLOCK) {
           bool ok = false;
           uint32_t c = 0;
@@ -928,8 +947,8 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
       }
       __syncthreads();  // final scores read before they are cleared
     }
-
     APSS_STAMP(4)
+
     // ---- re-zero what the round touched ----
     if (full_zero) {
       for (int i = tid * 4; i < cb; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
@@ -939,24 +958,26 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     }
     APSS_STAMP(5)
     if (tid == 0) {
-      // this parity's long list was consumed before the barrier above and is refilled during round q+1;
-      // the OTHER parity's flags were last read before the closing barrier of round q-1 and are next
-      // written after the closing barrier of this round, so they can be cleared here without a race
-      ctr[4 * par] = 0;
-      ctr[4 * (par ^ 1) + 1] = 0;
-      ctr[4 * (par ^ 1) + 2] = 0;
+      // this round's long list was consumed before the barrier above and is refilled (for round q+3) after the
+      // barrier below; the OTHER parity's flags were last read before the closing barrier of round q-1 and are
+      // next written after the closing barrier of this round: both can be cleared here without a race
+      ctr[l3] = 0;
+      ctr[4 + 2 * (par ^ 1)] = 0;
+      ctr[5 + 2 * (par ^ 1)] = 0;
     }
     __syncthreads();  // clears done before any add of round q+1
     APSS_STAMP(6)
 
-    wf = wfn;
-    P1 = P2;
-    I2 = I3;
+    wf0 = wf1;
+    wf1 = wf2;
+    P2 = P3;
+    I3 = I4;
     R1 = R2;
     R2 = R3;
     R3 = R4;
+    R4 = R5;
+    l3 = l3 == 2 ? 0 : l3 + 1;
   }
-
 #undef APSS_STAMP
   if (DIAG && ln == 0 && a.dbg)
     for (int k = 0; k < 8; ++k) atomicAdd(&a.dbg[k], tsum[k]);
