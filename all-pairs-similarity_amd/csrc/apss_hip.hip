@@ -42,7 +42,9 @@ struct apss_handle {
   bool nonneg = true;  // every stored / queried weight so far is >= 0
   int64_t store_max_nnz = 0, q_max_nnz = 0;  // longest row of the store / of the staged query batch
   float store_max_norm2 = 0.f, q_max_norm2 = 0.f;  // largest squared row norm (bounds every partial score)
-  int32_t cb = 32768;
+  int64_t store_nonempty = 0;  // stored rows with at least one indexed entry (each touches itself in a self-join)
+  int64_t last_batch_nonempty = 0;
+  int32_t cb = 16384;
 
   // store (CSR) -- vectorsStore, IWA:22
   int64_t n_rows = 0, nnz = 0;
@@ -176,7 +178,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   // destination
   int64_t dst_row0 = to_store ? h->n_rows : 0, dst_nnz0 = to_store ? h->nnz : 0;
   int64_t kept_rows = n, kept_nnz = nnz;
-  unsigned int flags_host[3] = {0, 0, 0};
+  unsigned int flags_host[4] = {0, 0, 0, 0};
   if (transform) {
     APSS_TRY(ensure(h, h->s_rowdst, (size_t)n + 1));
     APSS_TRY(ensure(h, h->s_nnzdst, (size_t)n + 1));
@@ -186,7 +188,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
     HIPCHK(h, hipMemcpyAsync(&kept_rows, h->s_rowdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&kept_nnz, h->s_nnzdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   }
-  HIPCHK(h, hipMemcpyAsync(flags_host, h->flagword.p, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(flags_host, h->flagword.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (flags_host[0] & 1u)
     return fail(h, APSS_E_INVALID, "malformed vector: indices must be strictly increasing and in [0, dim) "
@@ -198,6 +200,8 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   if (to_store) {
     h->store_max_nnz = std::max<int64_t>(h->store_max_nnz, flags_host[1]);
     h->store_max_norm2 = std::max(h->store_max_norm2, norm2);
+    h->store_nonempty += flags_host[3];
+    h->last_batch_nonempty = flags_host[3];
   } else {
     h->q_max_nnz = flags_host[1];
     h->q_max_norm2 = norm2;
@@ -363,7 +367,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const int wave_u = (variant == 'A' || variant == 'D') ? 8 : 5;
   const int wave_longcap = (variant == 'A' || variant == 'B') ? 256 : 128;
   const int wave_survcap = (variant == 'A' || variant == 'B') ? 1024 : 512;
-  const bool wave_path = mode == 0 && fx_scale > 0 && q_max_nnz <= wave_block && !(h->cfg.flags & APSS_FLAG_FORCE_GENERAL);
+  // chunk descriptors pack (first posting * 8 + count - 1) into 32 bits: a tile's postings must number < 2^28
+  const bool wave_path = mode == 0 && fx_scale > 0 && q_max_nnz <= wave_block && !(h->cfg.flags & APSS_FLAG_FORCE_GENERAL) &&
+                         h->store_max_nnz * (int64_t)h->cb < (1LL << 28);
   a.fx_scale = (float)fx_scale;
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::ceil(theta * fx_scale));
   const size_t lds = wave_path ? probe_wave_lds_bytes(h->cb, wave_block, wave_u, wave_longcap, wave_survcap)
@@ -435,6 +441,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     h->st.probe_launches++;
     h->st.posting_visits = (int64_t)c[kCtrVisits];
     h->st.candidate_pairs = (int64_t)c[kCtrCands];
+    // the speed path counts a stored query's touch of its own slot; it is not a (q, c != q) pair
+    if (wave_path && q_slot_base >= 0) h->st.candidate_pairs -= (q_slot_base == 0 && nq == h->n_rows) ? h->store_nonempty : h->last_batch_nonempty;
     h->st.result_pairs = (int64_t)c[kCtrResults];
     if (c[kCtrResults] <= a.res_cap) {
       h->n_res = (int64_t)c[kCtrResults];
@@ -543,7 +551,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
     return APSS_E_INVALID;
   }
   h->sharded = !(h->cfg.term_lo == 0 && h->cfg.term_hi == cfg->dim);
-  h->cb = cfg->tile_rows ? cfg->tile_rows : 32768;
+  h->cb = cfg->tile_rows ? cfg->tile_rows : 16384;
   if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {
     g_create_error = "tile_rows must be a multiple of 64 in [64, 32768]";
     delete h;
@@ -747,6 +755,7 @@ int32_t apss_clear(apss_handle *h) {
   h->nonneg = true;
   h->store_max_nnz = 0;
   h->store_max_norm2 = 0.f;
+  h->store_nonempty = 0;
   return APSS_OK;
 }
 

@@ -64,7 +64,7 @@ struct IngestArgs {
   int64_t *row_cnt;   // [n] kept entries (0 for dropped rows)
   float *row_inv;     // [n] 1/norm (1 when not normalising)
   float *row_sub;     // [n] L2 norm of the kept entries (the shard's sub-norm)
-  unsigned int *flags_out;  // [0]: bit0 malformed indices, bit1 non-finite value, bit2 negative value kept; [1]: max kept row length; [2]: bits of the max squared row norm
+  unsigned int *flags_out;  // [0]: bit0 malformed indices, bit1 non-finite value, bit2 negative value kept; [1]: max kept row length; [2]: bits of the max squared row norm; [3]: non-empty kept rows
 };
 
 // one 16-lane group per row
@@ -115,6 +115,7 @@ __global__ void k_ingest_count(IngestArgs a) {
     if (admit) {
       atomicMax(a.flags_out + 1, (unsigned)cnt);         // longest kept row: picks the probe kernel
       atomicMax(a.flags_out + 2, __float_as_uint(sub));  // largest squared L2 norm of a kept row (fixed-point range)
+      if (cnt > 0) atomicAdd(a.flags_out + 3, 1u);       // rows with at least one kept entry
     }
   }
 }
@@ -657,7 +658,7 @@ constexpr int kChunk = 8;        // postings per chunk: 8 lanes x 8 B = 64 B
 constexpr int kLongLenW = 256;   // longer segments are swept by the whole workgroup
 
 __host__ __device__ inline size_t probe_wave_lds_bytes(int cb, int block, int u, int longcap, int survcap) {
-  return ((size_t)(cb + kWave) * 4 + (size_t)(block / kWave) * (kWave / kChunk) * u * 16 + 3 * (size_t)longcap * 12 +
+  return ((size_t)(cb + kWave) * 4 + (size_t)(block / kWave) * (kWave / kChunk) * u * 8 + 3 * (size_t)longcap * 12 +
           (size_t)survcap * 4 + 128 + 15) / 16 * 16;
 }
 
@@ -674,21 +675,23 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 
 // LONGCAP: long segments per round kept in the workgroup list (more stay with their wave); SURVCAP: threshold
 // crossings per round kept in LDS (more: the round falls back to scanning the accumulators)
+typedef unsigned int apss_u32x2 __attribute__((ext_vector_type(2)));
+
 template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool DIAG = false>
 __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
-  constexpr int kLongCapW = LONGCAP;
   constexpr int GPW = kWave / kChunk;  // chunk groups per wave step (8)
   constexpr int WIN = GPW * U;         // chunks in one wave's register window
   static_assert(WIN <= kWave, "the window strip is cleared by one store per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint32_t *acc = (uint32_t *)smem_raw;                    // [cb] accumulators + [64] per-lane dummy slots
-  uint4 *items = (uint4 *)(acc + a.cb + kWave);            // [NW][WIN] {first posting, count, weight bits, -}
-  uint2 *longs = (uint2 *)(items + NW * WIN);              // [3][kLongCapW]
-  float *long_w = (float *)(longs + 3 * kLongCapW);        // [3][kLongCapW]
-  uint32_t *surv = (uint32_t *)(long_w + 3 * kLongCapW);   // [SURVCAP]
+  uint32_t *acc = (uint32_t *)smem_raw;                  // [cb] accumulators (+ 64 words of slack)
+  uint2 *items = (uint2 *)(acc + a.cb + kWave);          // [NW][WIN] {first posting * 8 + (count - 1), weight bits}
+  uint2 *longs = (uint2 *)(items + NW * WIN);            // [3][LONGCAP]
+  float *long_w = (float *)(longs + 3 * LONGCAP);        // [3][LONGCAP]
+  uint32_t *surv = (uint32_t *)(long_w + 3 * LONGCAP);   // [SURVCAP]
   // ctr[0..2] long segments of round (r % 3); ctr[4 + 2p] "clear whole tile", ctr[5 + 2p] survivors (p = r & 1)
   uint32_t *ctr = surv + SURVCAP;
+  uint32_t n_long_next = 0;  // long segments of the coming round, read behind the previous round's barrier
   unsigned long long *stat = reinterpret_cast<unsigned long long *>(ctr + 8);
 
   const int tid = threadIdx.x;
@@ -698,69 +701,81 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   const int chunk = blockIdx.x % a.n_chunks;
   const int q0 = chunk * a.q_chunk;
   const int q1 = min(a.nq, q0 + a.q_chunk);
-  const uint32_t *tp = a.tile_ptr + (int64_t)tile * a.tp_stride;
   const int64_t tile_row0 = (int64_t)tile * cb;
-  const Posting *post = a.post + a.store_rowptr[tile_row0];
+  const int64_t tile_row1 = min(tile_row0 + cb, a.n_rows);
   const float tile_scale = a.tile_scale ? a.tile_scale[tile] : 1.0f;
-  const int kterm = ln * NW + wv;              // the term of the query this lane looks after
-  const uint32_t dummy = (uint32_t)(cb + ln);  // where an idle lane's +0 lands (conflict-free, stays 0)
-  const uint32_t lo = (uint32_t)(ln % kChunk); // posting of the chunk this lane handles
-  uint4 *wl = items + wv * WIN;                // this wave's chunk strip
+  const int kterm = ln * NW + wv;               // the term of the query this lane looks after
+  const uint32_t lo = (uint32_t)(ln % kChunk);  // posting of the chunk this lane handles
+  uint2 *wl = items + wv * WIN;                 // this wave's chunk strip
   const float fxs = a.fx_scale, fxinv = 1.0f / a.fx_scale;
+
+  // buffer descriptors built from wave-uniform values only (32-bit offsets, hardware range check: a read past
+  // the end returns 0, which is what makes every load below unconditional and every address clamp-free)
+  const int64_t qbase = a.q_rowptr[q0], qend = a.q_rowptr[q1];
+  const int64_t pbase = a.store_rowptr[tile_row0], pend = a.store_rowptr[tile_row1];
+  const __amdgpu_buffer_rsrc_t rs_qi =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_idx + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_qv =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_val + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_tp = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.tile_ptr + (int64_t)tile * a.tp_stride), 0, (int)(a.tp_stride * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_po =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.post + pbase), 0, (int)((pend - pbase) * 8), 0x00020000);
+  constexpr uint32_t kOob = 0xfffffff0u;  // an offset no descriptor covers
 
   for (int i = tid * 4; i < cb + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 16) ctr[tid] = 0;
-  unsigned long long my_visits = 0, my_cands = 0;
+  unsigned long long my_visits = 0;
+  uint32_t my_cands = 0;  // first touches seen by this lane (< 2^32 per workgroup chunk)
 
-  // ---- pipeline stages (all loads unconditional with clamped addresses so the compiler can count them) ----
-  struct RowExt { int64_t qb; int nnz; };
-  struct TermW { int32_t term; float w; bool valid; };
+  // ---- pipeline stages ----
+  struct RowExt { int qb; int nnz; };  // qb relative to qbase
+  struct TermW { uint32_t term; float w; bool valid; };
   struct Seg { uint32_t s, len; float w; };
   struct WaveWork {
     uint32_t s, len, excl;  // per lane: its term's segment and the number of chunks of the lanes before it
     float w;                // per lane: query weight of its term
     int totch;              // wave-uniform: chunks of this wave this round
     int tw;                 // wave-uniform: terms of this wave this round
-    Posting pc[U];          // prefetched postings: step u, chunk u * GPW + lane / kChunk, posting lane % kChunk
-    float wq[U];            // query weight of that chunk's term, pre-multiplied by fx_scale
-    uint32_t act;           // bit u: step u holds a real posting in this lane
+    apss_u32x2 pc[U];       // prefetched postings {slot, weight bits}: step u, chunk u * GPW + lane / 8, posting lane % 8
+    float wq[U];            // query weight of that chunk's term times fx_scale; 0 in lanes past the chunk's end
   };
   auto load_R = [&](int q) {
     RowExt r;
     const int qq = min(q, a.nq - 1);
-    r.qb = a.q_rowptr[qq];
-    const int64_t qe = a.q_rowptr[qq + 1];
-    r.nnz = q < q1 ? (int)(qe - r.qb) : 0;
+    const int64_t b = a.q_rowptr[qq], e = a.q_rowptr[qq + 1];
+    r.qb = (int)(b - qbase);
+    r.nnz = q < q1 ? (int)(e - b) : 0;
     return r;
   };
   auto load_I = [&](const RowExt &r) {
     TermW t;
     t.valid = kterm < r.nnz;
-    int64_t ii = r.qb + (t.valid ? kterm : 0);
-    ii = ii < a.q_nnz_end ? ii : a.q_nnz_end - 1;  // an empty last row starts one past the end
-    t.term = a.q_idx[ii];
-    t.w = a.q_val[ii];
+    const uint32_t off = t.valid ? (uint32_t)(r.qb + kterm) * 4u : kOob;
+    t.term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
+    t.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0));
     return t;
   };
   auto load_P = [&](const TermW &t) {
     Seg g;
-    const uint32_t b = tp[t.term], e = tp[t.term + 1];
-    g.s = b;
-    g.len = t.valid ? e - b : 0u;
+    const apss_u32x2 be = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, t.term * 4u, 0, 0);  // {tp[term], tp[term + 1]}
+    g.s = be.x;
+    g.len = t.valid ? be.y - be.x : 0u;
     g.w = t.w;
     return g;
   };
-  auto flatten = [&](const Seg &g, const RowExt &r, int li) {
-    WaveWork f;
+  // Cut the wave's segments into 8-posting chunks, number them with a wave prefix sum, keep the descriptors of the
+  // first WIN chunks in the wave's LDS strip, and request the postings of those chunks (8 lanes per chunk).
+  auto flatten = [&](WaveWork &f, const Seg &g, const RowExt &r, int li) {
     uint32_t len = g.len;
     my_visits += len;
     if (len > (uint32_t)kLongLenW) {  // swept by the whole workgroup in its own round
       const uint32_t k = atomicAdd(&ctr[li], 1u);
-      if (k < (uint32_t)kLongCapW) {
-        longs[li * kLongCapW + k] = make_uint2(g.s, len);
-        long_w[li * kLongCapW + k] = g.w;
+      if (k < (uint32_t)LONGCAP) {
+        longs[li * LONGCAP + k] = make_uint2(g.s, len);
+        long_w[li * LONGCAP + k] = g.w;
         len = 0;
-      }  // else: the list is full, the segment stays with this wave (slow path below)
+      }  // else: the list is full, the segment stays with this wave (slow path)
     }
     const uint32_t nch = (len + kChunk - 1) / kChunk;
     const uint32_t incl = wave_incl_scan(nch);
@@ -771,30 +786,33 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     f.w = g.w;
     f.tw = wv < r.nnz ? (r.nnz - wv + NW - 1) / NW : 0;
     f.totch = __builtin_amdgcn_readlane((int)incl, kWave - 1);
-    // chunk descriptors into the wave's strip: clear it, then every lane adds the chunks of its own segment
-    if (ln < WIN) wl[ln] = make_uint4(0u, 0u, 0u, 0u);
+    // clear the strip (an all-zero descriptor has weight 0: it adds 0 to the slot of posting 0), then every lane
+    // stores the chunks of its own segment; LDS operations of one wave execute in order, so the reads see them
+    if (ln < WIN) wl[ln] = make_uint2(0u, 0u);
     const uint32_t wbits = __float_as_uint(fxs * g.w);
-    for (uint32_t k = 0;; ++k) {
-      const bool more = k < nch && excl + k < (uint32_t)WIN;
-      if (!__any(more)) break;
-      if (more) wl[excl + k] = make_uint4(g.s + k * kChunk, min((uint32_t)kChunk, len - k * kChunk), wbits, 0u);
-    }
-    // (LDS operations of one wave execute in order: the reads below see the stores above)
-    f.act = 0;
+    auto put = [&](const uint32_t k) {
+      if (k < nch && excl + k < (uint32_t)WIN)
+        wl[excl + k] = make_uint2((g.s + k * kChunk) * 8u + (min((uint32_t)kChunk, len - k * kChunk) - 1u), wbits);
+    };
+    put(0);
+    put(1);
+    put(2);
+    if (__any(nch > 3u))  // rare: a segment of more than 24 postings in a 16384-row tile
+      for (uint32_t k = 3; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint4 it = wl[u * GPW + ln / kChunk];
-      f.wq[u] = __uint_as_float(it.z);
-      f.pc[u] = post[it.x + lo];  // an empty descriptor reads post[lo]: valid memory, masked below
-      if (lo < it.y) f.act |= 1u << u;
+      uint2 it = wl[u * GPW + ln / kChunk];
+      asm volatile("" : "+v"(it.x), "+v"(it.y));                     // one ds_read_b64, not a branch around half of it
+      const uint32_t c1 = it.x & 7u;                                  // postings in the chunk - 1
+      f.wq[u] = lo <= c1 ? __uint_as_float(it.y) : 0.0f;             // 0 marks the lanes past the chunk's end
+      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (it.x ^ c1) + lo * 8u, 0, 0);
     }
-    return f;
   };
 
   RowExt R1 = load_R(q0 + 1), R2 = load_R(q0 + 2), R3 = load_R(q0 + 3), R4 = load_R(q0 + 4);
   TermW I3, I4;
   Seg P2, P3;
-  WaveWork wf0, wf1;
+  WaveWork wfa, wfb, wfc;
   {
     const RowExt R0 = load_R(q0);
     const TermW I0 = load_I(R0), I1 = load_I(R1), I2 = load_I(R2);
@@ -802,10 +820,11 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     const Seg P0 = load_P(I0), P1 = load_P(I1);
     P2 = load_P(I2);
     __syncthreads();  // counters zeroed before the first long-segment pushes
-    wf0 = flatten(P0, R0, 0);
-    wf1 = flatten(P1, R1, 1);
+    flatten(wfa, P0, R0, 0);
+    flatten(wfb, P1, R1, 1);
   }
   __syncthreads();  // accumulators cleared, long lists of rounds 0 and 1 complete
+  n_long_next = ctr[0];
 
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define APSS_STAMP(k)                                   \
@@ -814,65 +833,67 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     tsum[k] += t_ - tprev;                              \
     tprev = t_;                                         \
   }
-  int l3 = 0;  // (q - q0) % 3
-  for (int q = q0; q < q1; ++q) {
+  // One round: query q against this tile.  w0 holds round q's prefetched work, w2 receives round q+2's; l3 is
+  // (q - q0) % 3, a compile-time constant because the loop below is unrolled three times with the three
+  // WaveWork register sets rotating by name (no register copies).
+  auto round = [&](WaveWork &w0, WaveWork &w2, const int q, const int l3) {
     unsigned long long tprev = DIAG ? clock64() : 0;
     const int par = (q - q0) & 1;
     const float qs = a.q_scale ? a.q_scale[q] : 1.0f;
     const float thr = a.theta * qs * tile_scale;
     // shard mode: the candidate test is a necessary condition that is verified exactly later, so round it down
     const uint32_t thr_fx = (a.q_scale || a.tile_scale) ? (uint32_t)(thr * fxs * 0.999999f) : a.theta_fx;
-    const int64_t sl64 = a.q_slot_base >= 0 ? a.q_slot_base + q - tile_row0 : -1;
-    const uint32_t self_local = (sl64 >= 0 && sl64 < cb) ? (uint32_t)sl64 : 0xffffffffu;
+    const uint32_t thr1 = thr_fx - 1u;  // theta > 0 => thr_fx >= 1
 
     // ---- stage loads for the rounds ahead ----
     const RowExt R5 = load_R(q + 5);
     I4 = load_I(R4);
     P3 = load_P(I3);
-    const int l3n = l3 == 0 ? 2 : l3 - 1;  // (l3 + 2) % 3
-    WaveWork wf2 = flatten(P2, R2, l3n);
+    flatten(w2, P2, R2, l3 == 0 ? 2 : l3 - 1);
     APSS_STAMP(0)
 
     // ---- accumulate round q ----
-    auto check = [&](const uint32_t slot, const uint32_t p, const uint32_t old) {
-      my_cands += (old == 0u && slot != self_local) ? 1u : 0u;
-      if (old < thr_fx && old + p >= thr_fx) {  // this add took the candidate across the threshold
+    // old < thr <= old + p  <=>  (thr - 1 - old) < p in unsigned arithmetic: this add crossed the threshold
+    auto crossed = [&](const uint32_t slot, const uint32_t p, const uint32_t old) {
+      if (thr1 - old < p) {
         const uint32_t k = atomicAdd(&ctr[5 + 2 * par], 1u);
         if (k < (uint32_t)SURVCAP) surv[k] = slot;
       }
     };
-    auto visit = [&](const Posting pc, const float wqs) {
-      const uint32_t p = __float2uint_rn(wqs * pc.w);
-      check(pc.slot, p, atomicAdd(&acc[pc.slot], p));
+    auto visit = [&](const apss_u32x2 pc, const float wqs) {
+      const uint32_t p = (uint32_t)__builtin_fmaf(wqs, __uint_as_float(pc.y), 0.5f);
+      const uint32_t old = atomicAdd(&acc[pc.x], p);
+      my_cands += old == 0u ? 1u : 0u;
+      crossed(pc.x, p, old);
     };
-    uint32_t sl[U];
     {
-      // the register window: all LDS atomics issued back to back, one wait, then the threshold checks
+      // the register window: LDS atomics of every real posting issued back to back, then the threshold checks.
+      // Lanes past a chunk's end (weight 0) stay out of the atomics: fewer LDS bank conflicts, exact counts.
       uint32_t p[U], old[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool on = (wf0.act >> u) & 1u;
-        sl[u] = on ? wf0.pc[u].slot : dummy;
-        p[u] = on ? __float2uint_rn(wf0.wq[u] * wf0.pc[u].w) : 0u;
+        p[u] = (uint32_t)__builtin_fmaf(w0.wq[u], __uint_as_float(w0.pc[u].y), 0.5f);
+        old[u] = 1u;
+        if (w0.wq[u] != 0.0f) old[u] = atomicAdd(&acc[w0.pc[u].x], p[u]);  // ds_add_rtn_u32
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) old[u] = atomicAdd(&acc[sl[u]], p[u]);  // ds_add_rtn_u32
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if ((wf0.act >> u) & 1u) check(sl[u], p[u], old[u]);
+      for (int u = 0; u < U; ++u) {
+        my_cands += old[u] == 0u ? 1u : 0u;  // first touch of this candidate in this round
+        if (w0.wq[u] != 0.0f) crossed(w0.pc[u].x, p[u], old[u]);
+      }
     }
     APSS_STAMP(1)
-    if (wf0.totch > WIN) {  // wave-uniform: more chunks than the register window holds
+    if (w0.totch > WIN) {  // wave-uniform: more chunks than the register window holds
       if (ln == 0) ctr[4 + 2 * par] = 1;
-      for (int c0 = WIN; c0 < wf0.totch; c0 += GPW) {
+      for (int c0 = WIN; c0 < w0.totch; c0 += GPW) {
         const uint32_t c = (uint32_t)(c0 + ln / kChunk);
         uint32_t st = 0, cn = 0;
         float wq_ = 0.f;
-        for (int m = 0; m < wf0.tw; ++m) {
-          const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)wf0.excl, m);
-          const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)wf0.len, m);
-          const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)wf0.s, m);
-          const float wm = fxs * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wf0.w), m));
+        for (int m = 0; m < w0.tw; ++m) {
+          const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)w0.excl, m);
+          const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)w0.len, m);
+          const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)w0.s, m);
+          const float wm = fxs * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0.w), m));
           const uint32_t nm = (lm + kChunk - 1) / kChunk;
           const bool sel = c >= em && c < em + nm;
           const uint32_t k = c - em;
@@ -880,23 +901,25 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
           cn = sel ? min((uint32_t)kChunk, lm - k * kChunk) : cn;
           wq_ = sel ? wm : wq_;
         }
-        if (lo < cn) visit(post[st + lo], wq_);
+        if (lo < cn) visit(__builtin_amdgcn_raw_buffer_load_b64(rs_po, (st + lo) * 8u, 0, 0), wq_);
       }
     }
-    const uint32_t n_long = min(ctr[l3], (uint32_t)kLongCapW);
+    const uint32_t n_long = min(n_long_next, (uint32_t)LONGCAP);
     for (uint32_t j = 0; j < n_long; ++j) {
-      const uint2 sgm = longs[l3 * kLongCapW + j];
-      const float wq_ = fxs * long_w[l3 * kLongCapW + j];
+      const uint2 sgm = longs[l3 * LONGCAP + j];
+      const float wq_ = fxs * long_w[l3 * LONGCAP + j];
       uint32_t k = tid;
       for (; k + 3 * BLOCK < sgm.y; k += 4 * BLOCK) {  // four loads in flight per lane
-        const Posting p0 = post[sgm.x + k], p1 = post[sgm.x + k + BLOCK], p2 = post[sgm.x + k + 2 * BLOCK],
-                      p3 = post[sgm.x + k + 3 * BLOCK];
+        const apss_u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 8u, 0, 0),
+                         p1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + BLOCK) * 8u, 0, 0),
+                         p2 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2 * BLOCK) * 8u, 0, 0),
+                         p3 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 3 * BLOCK) * 8u, 0, 0);
         visit(p0, wq_);
         visit(p1, wq_);
         visit(p2, wq_);
         visit(p3, wq_);
       }
-      for (; k < sgm.y; k += BLOCK) visit(post[sgm.x + k], wq_);
+      for (; k < sgm.y; k += BLOCK) visit(__builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 8u, 0, 0), wq_);
     }
     APSS_STAMP(2)
     __syncthreads();  // every add of round q has landed
@@ -904,6 +927,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
 
     // ---- threshold prune + compaction (IWA:93-95) ----
     const uint2 fl = *reinterpret_cast<const uint2 *>(&ctr[4 + 2 * par]);  // {clear-whole-tile flag, survivors}
+    n_long_next = ctr[l3 == 2 ? 0 : l3 + 1];  // complete since round q-1's pushes; same LDS wait as the flags
     const uint32_t n_surv = fl.y;
     const bool full_zero = n_long > 0 || fl.x != 0 || n_surv > (uint32_t)SURVCAP;
     if (n_surv > 0) {
@@ -949,12 +973,13 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     }
     APSS_STAMP(4)
 
-    // ---- re-zero what the round touched ----
+    // ---- re-zero exactly the slots the round touched ----
     if (full_zero) {
       for (int i = tid * 4; i < cb; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
     } else {
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc[sl[u]] = 0u;
+      for (int u = 0; u < U; ++u)
+        if (w0.wq[u] != 0.0f) acc[w0.pc[u].x] = 0u;
     }
     APSS_STAMP(5)
     if (tid == 0) {
@@ -968,15 +993,19 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     __syncthreads();  // clears done before any add of round q+1
     APSS_STAMP(6)
 
-    wf0 = wf1;
-    wf1 = wf2;
     P2 = P3;
     I3 = I4;
     R1 = R2;
     R2 = R3;
     R3 = R4;
     R4 = R5;
-    l3 = l3 == 2 ? 0 : l3 + 1;
+  };
+  for (int q = q0; q < q1; q += 3) {
+    round(wfa, wfc, q, 0);
+    if (q + 1 >= q1) break;
+    round(wfb, wfa, q + 1, 1);
+    if (q + 2 >= q1) break;
+    round(wfc, wfb, q + 2, 2);
   }
 #undef APSS_STAMP
   if (DIAG && ln == 0 && a.dbg)
@@ -985,7 +1014,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   if (tid < 3) stat[tid] = 0;
   __syncthreads();
   atomicAdd(&stat[0], my_visits);
-  atomicAdd(&stat[1], my_cands);
+  atomicAdd(&stat[1], (unsigned long long)my_cands);
   __syncthreads();
   if (tid == 0) {
     atomicAdd(&a.counters[kCtrVisits], stat[0]);

@@ -167,7 +167,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s: N=%d dim=%d nnz=%d %s theta=%g, single-batch self-join (build + probe)" % (
             a.workload, n, cfg["dim"], cfg["nnz"], "Zipf(%g)" % cfg["zipf_s"] if cfg["zipf_s"] else "uniform",
-            cfg["theta"]), "parallelism": parallelism, "tile_rows": a.tile_rows or 32768},
+            cfg["theta"]), "parallelism": parallelism, "tile_rows": a.tile_rows or 16384},
         "posting_visits_per_step": visits,
         "candidate_pairs_per_step": cands,
         "result_pairs_per_step": int(n_pairs),

@@ -62,7 +62,7 @@ typedef struct apss_config {
   int32_t term_lo;         /* term-range shard [term_lo, term_hi): only these dims are indexed and scored */
   int32_t term_hi;         /*   (0, 0) or (0, dim) = the whole term space (single GPU) */
   int32_t tile_rows;       /* candidate tile = rows whose fp32 accumulators share one workgroup's LDS;
-                              0 = default (32768); must be a multiple of 64 and <= 32768 */
+                              0 = default (16384: two workgroups share a CU's 160 KB of LDS); a multiple of 64, <= 32768 */
   int32_t reserved0;
   int64_t capacity_rows;   /* hints for the initial HBM reservation (0 = grow on demand) */
   int64_t capacity_nnz;
