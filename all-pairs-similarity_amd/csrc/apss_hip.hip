@@ -53,9 +53,12 @@ struct apss_handle {
   DevBuf<float> val, sub;  // sub: shard sub-norm per row (sharded only)
   // index (tile-major CSC) -- invertedIndex, IWA:25
   int64_t n_tiles = 0;
-  DevBuf<uint32_t> tile_ptr;
+  int64_t post_used = 0;  // posting records incl. segment alignment padding
+  DevBuf<uint2> tile_seg;
   DevBuf<Posting> post;
   DevBuf<float> tile_min;
+  DevBuf<int64_t> tile_base, tile_total;  // device: first posting of each tile (+ end), padded posting counts
+  std::vector<int64_t> h_tile_base;       // host mirror of tile_base
   // query staging (apss_query: batch not stored)
   DevBuf<int64_t> q_rowptr, q_ext;
   DevBuf<int32_t> q_idx;
@@ -252,14 +255,17 @@ int32_t build_tiles(apss_handle *h, int64_t row0) {
   const int64_t cb = h->cb;
   const int64_t tile0 = row0 / cb;
   const int64_t n_tiles = ceil_div(h->n_rows, cb);
-  const int64_t stride = (int64_t)h->cfg.dim + 2;
-  APSS_TRY(ensure(h, h->tile_ptr, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
-  if (h->post.cap < (size_t)h->nnz + 64) return fail(h, APSS_E_STATE, "postings not reserved");
-  if (h->sharded) APSS_TRY(ensure(h, h->tile_min, (size_t)n_tiles, (size_t)tile0));
+  const int64_t stride = (int64_t)h->cfg.dim;
   h->n_tiles = n_tiles;
   if (n_tiles == tile0) return APSS_OK;
+  APSS_TRY(ensure(h, h->tile_seg, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
+  APSS_TRY(ensure(h, h->tile_base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
+  APSS_TRY(ensure(h, h->tile_total, (size_t)n_tiles, 0));
+  if (h->sharded) APSS_TRY(ensure(h, h->tile_min, (size_t)n_tiles, (size_t)tile0));
+  if (h->h_tile_base.empty()) h->h_tile_base.push_back(0);
+  h->h_tile_base.resize((size_t)tile0 + 1);  // bases of the tiles that stay
   const int64_t r0 = tile0 * cb;
-  HIPCHK(h, hipMemsetAsync(h->tile_ptr.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->tile_seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
   BuildArgs b{};
   b.rowptr = h->rowptr.p;
   b.idx = h->idx.p;
@@ -268,15 +274,26 @@ int32_t build_tiles(apss_handle *h, int64_t row0) {
   b.row1 = h->n_rows;
   b.cb = (int32_t)cb;
   b.dim = h->cfg.dim;
-  b.tile_ptr = h->tile_ptr.p;
-  b.tp_stride = stride;
-  b.post = h->post.p;
+  b.tile_seg = h->tile_seg.p;
+  b.seg_stride = stride;
   const int threads = 256;
   const int64_t blocks = ceil_div((h->n_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
-  hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, h->tile_ptr.p, stride,
-                     h->cfg.dim, tile0);
+  hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, h->tile_seg.p, stride,
+                     h->cfg.dim, tile0, h->tile_total.p);
+  HIPCHK(h, hipGetLastError());
+  // padded posting counts -> tile bases (host prefix sum: a handful of values), then reserve the posting array
+  std::vector<int64_t> tot((size_t)(n_tiles - tile0));
+  HIPCHK(h, hipMemcpyAsync(tot.data(), h->tile_total.p + tile0, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < tot.size(); ++i) h->h_tile_base.push_back(h->h_tile_base.back() + tot[i]);
+  HIPCHK(h, hipMemcpyAsync(h->tile_base.p + tile0, h->h_tile_base.data() + tile0, (size_t)(n_tiles - tile0 + 1) * sizeof(int64_t),
+                           hipMemcpyHostToDevice, h->stream));
+  h->post_used = h->h_tile_base.back();
+  APSS_TRY(ensure(h, h->post, (size_t)h->post_used + 64, (size_t)h->h_tile_base[(size_t)tile0]));
+  b.tile_post_base = h->tile_base.p;
+  b.post = h->post.p;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
   if (h->sharded)
     hipLaunchKernelGGL(k_tile_min_sub, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream,
@@ -288,11 +305,6 @@ int32_t build_tiles(apss_handle *h, int64_t row0) {
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->st.build_ms = ms;
   return APSS_OK;
-}
-
-// the store's postings array must keep earlier tiles when it is reallocated: ensure() with keep
-int32_t reserve_postings(apss_handle *h, int64_t new_nnz, int64_t keep_nnz) {
-  return ensure(h, h->post, (size_t)new_nnz + 64, (size_t)keep_nnz);  // + pad: clamped prefetch loads may read post[end]
 }
 
 template <int MODE>
@@ -329,10 +341,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   else mode = 0;
 
   ProbeArgs a{};
-  a.tile_ptr = h->tile_ptr.p;
-  a.tp_stride = (int64_t)h->cfg.dim + 2;
+  a.tile_seg = h->tile_seg.p;
+  a.seg_stride = (int64_t)h->cfg.dim;
   a.post = h->post.p;
-  a.store_rowptr = h->rowptr.p;
+  a.tile_post_base = h->tile_base.p;
   a.ext_id = h->ext.p;
   a.c_scale = h->sharded ? h->sub.p : nullptr;
   a.tile_scale = h->sharded ? h->tile_min.p : nullptr;
@@ -369,29 +381,29 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const int wave_survcap = (variant == 'A' || variant == 'B') ? 1024 : 512;
   // chunk descriptors pack (first posting * 8 + count - 1) into 32 bits: a tile's postings must number < 2^28
   const bool wave_path = mode == 0 && fx_scale > 0 && q_max_nnz <= wave_block && !(h->cfg.flags & APSS_FLAG_FORCE_GENERAL) &&
-                         h->store_max_nnz * (int64_t)h->cb < (1LL << 28);
+                         h->store_max_nnz * (int64_t)h->cb + (int64_t)kSegAlign * h->cfg.dim < (1LL << 28);
   a.fx_scale = (float)fx_scale;
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::ceil(theta * fx_scale));
   const size_t lds = wave_path ? probe_wave_lds_bytes(h->cb, wave_block, wave_u, wave_longcap, wave_survcap)
                                : probe_lds_bytes(h->cb, kProbeBlock, mode);
   auto launch_wave = [&](bool diag) -> int32_t {
     const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
+#define APSS_LAUNCH_WAVE1(B, UU, LC, SC, SH, DG)                                                                         \
+    do {                                                                                                                   \
+      auto kern = k_probe_wave<B, UU, LC, SC, SH, DG>;                                                                     \
+      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL(kern, grid, dim3(B), lds, h->stream, a);                                                          \
+    } while (0)
 #define APSS_LAUNCH_WAVE(B, UU, LC, SC)                                                                                  \
     do {                                                                                                                   \
-      if (diag) {                                                                                                          \
-        auto kern = k_probe_wave<B, UU, LC, SC, true>;                                                                     \
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, dim3(B), lds, h->stream, a);                                                        \
-      } else {                                                                                                             \
-        auto kern = k_probe_wave<B, UU, LC, SC, false>;                                                                    \
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, dim3(B), lds, h->stream, a);                                                        \
-      }                                                                                                                    \
+      if (h->sharded) { if (diag) APSS_LAUNCH_WAVE1(B, UU, LC, SC, true, true); else APSS_LAUNCH_WAVE1(B, UU, LC, SC, true, false); } \
+      else { if (diag) APSS_LAUNCH_WAVE1(B, UU, LC, SC, false, true); else APSS_LAUNCH_WAVE1(B, UU, LC, SC, false, false); }          \
     } while (0)
     if (variant == 'A') APSS_LAUNCH_WAVE(512, 8, 256, 1024);
     else if (variant == 'B') APSS_LAUNCH_WAVE(1024, 5, 256, 1024);
     else if (variant == 'C') APSS_LAUNCH_WAVE(512, 5, 128, 512);
     else APSS_LAUNCH_WAVE(256, 8, 128, 512);
+#undef APSS_LAUNCH_WAVE1
 #undef APSS_LAUNCH_WAVE
     HIPCHK(h, hipGetLastError());
     return APSS_OK;
@@ -497,19 +509,11 @@ int32_t insert_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d
   *first_new_row = h->n_rows;
   if (n == 0) return APSS_OK;
   if (h->n_rows + n > 0x7fffffffLL) return fail(h, APSS_E_INVALID, "more than 2^31 - 1 vectors in one handle");
-  // postings of the tiles that stay must survive growth of the array
-  const int64_t keep_rows = h->n_rows / h->cb * h->cb;
-  int64_t keep_nnz = 0;
-  if (keep_rows > 0 && h->post.cap < (size_t)(h->nnz + nnz)) {
-    HIPCHK(h, hipMemcpyAsync(&keep_nnz, h->rowptr.p + keep_rows, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-  }
   int64_t kept_rows = 0, kept_nnz = 0;
   APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, true, &kept_rows, &kept_nnz));
   const int64_t row0 = h->n_rows;
   h->n_rows += kept_rows;
   h->nnz += kept_nnz;
-  APSS_TRY(reserve_postings(h, h->nnz, keep_nnz));
   APSS_TRY(build_tiles(h, row0));
   return APSS_OK;
 }
@@ -589,7 +593,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   if (cfg->capacity_nnz > 0) {
     if (ensure(h, h->idx, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
         ensure(h, h->val, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
-        ensure(h, h->post, (size_t)cfg->capacity_nnz + 64, 0, true) != APSS_OK) {
+        ensure(h, h->post, (size_t)cfg->capacity_nnz + (size_t)cfg->capacity_nnz / 2 + 64, 0, true) != APSS_OK) {
       g_create_error = h->err;
       apss_destroy(h);
       return APSS_E_NOMEM;
@@ -604,7 +608,7 @@ void apss_destroy(apss_handle *h) {
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   release(h->rowptr); release(h->ext); release(h->idx); release(h->val); release(h->sub);
-  release(h->tile_ptr); release(h->post); release(h->tile_min);
+  release(h->tile_seg); release(h->post); release(h->tile_min); release(h->tile_base); release(h->tile_total);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
   release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val);
@@ -751,6 +755,8 @@ int32_t apss_clear(apss_handle *h) {
   h->n_rows = 0;
   h->nnz = 0;
   h->n_tiles = 0;
+  h->post_used = 0;
+  h->h_tile_base.clear();
   h->n_res = -1;
   h->nonneg = true;
   h->store_max_nnz = 0;

@@ -11,7 +11,8 @@
 //
 // Data layout in HBM: the store is CSR (int64 rowptr, int32 idx, fp32 val, int64 ext id); the index
 // is tile-major CSC: candidate slots are cut into tiles of `cb` consecutive rows, tile T owns the posting
-// records {u32 local slot, f32 weight} of its rows grouped by term, and a u32 offset table tile_ptr[T][dim+2].
+// records {u32 local slot, f32 weight} of its rows grouped by term, every (tile, term) segment starting on a 128-B
+// boundary (16 postings), and a table tile_seg[T][dim] of {first posting, length} per term.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -199,8 +200,12 @@ __global__ __launch_bounds__(1024) void k_scan_i64(const int64_t *in, int64_t *o
 
 // ---------------------------------------------------------------------------------------------------------
 // index build (IWA:61-71): for rows [row0, row1) of the store, fill the posting lists of their tiles.
-// tile_ptr row layout (u32[dim + 2]): after k_tile_hist tp[t + 2] = df_t in the tile; k_tile_scan makes
-// tp[t + 1] = first posting of term t; k_tile_scatter's cursor increments leave tp[t] = first, tp[t + 1] = end.
+// tile_seg[T][t] = {first posting, length} of term t in tile T, relative to the tile's posting base.  Every
+// segment starts on a 128-B boundary (a multiple of kSegAlign postings): an L2 line then never straddles two
+// segments, which cut the probe's memory-side traffic by a quarter (profiles/r01_summary.md).
+// k_tile_hist counts lengths into .y; k_tile_scan turns them into aligned starts (.x) and clears .y;
+// k_tile_scatter's cursor increments rebuild .y while placing the postings.
+constexpr int kSegAlign = 16;
 
 struct BuildArgs {
   const int64_t *rowptr;
@@ -209,9 +214,10 @@ struct BuildArgs {
   int64_t row0, row1;
   int32_t cb;
   int32_t dim;
-  uint32_t *tile_ptr;
-  int64_t tp_stride;  // dim + 2
-  Posting *post;      // same indexing as idx/val: tile T's postings live at [rowptr[T*cb], rowptr[min((T+1)*cb, n)))
+  uint2 *tile_seg;
+  int64_t seg_stride;             // dim
+  const int64_t *tile_post_base;  // [n_tiles + 1] first posting of each tile in `post`
+  Posting *post;
 };
 
 // one wave per row: coalesced reads of the row's entries
@@ -219,21 +225,21 @@ __global__ void k_tile_hist(BuildArgs a) {
   const int64_t row = a.row0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const int lane = threadIdx.x % kWave;
   if (row >= a.row1) return;
-  uint32_t *tp = a.tile_ptr + (row / a.cb) * a.tp_stride;
+  uint2 *sg = a.tile_seg + (row / a.cb) * a.seg_stride;
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
-  for (int64_t k = b + lane; k < e; k += kWave) atomicAdd(&tp[a.idx[k] + 2], 1u);
+  for (int64_t k = b + lane; k < e; k += kWave) atomicAdd(&sg[a.idx[k]].y, 1u);
 }
 
-// one workgroup per tile: in-place inclusive scan of tp[1 .. dim+1]
-__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *tile_ptr, int64_t tp_stride, int32_t dim, int64_t tile0) {
+// one workgroup per tile: exclusive scan of the aligned lengths; tile_total[tile] = postings incl. padding
+__global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0,
+                                                    int64_t *tile_total) {
   __shared__ uint32_t part[1024];
-  uint32_t *tp = tile_ptr + (tile0 + blockIdx.x) * tp_stride + 1;
+  uint2 *sg = tile_seg + (tile0 + blockIdx.x) * seg_stride;
   const int tid = threadIdx.x;
-  const int32_t n = dim + 1;
-  const int32_t per = (n + 1023) / 1024;
-  const int32_t b = tid * per, e = b + per < n ? b + per : n;
+  const int32_t per = (dim + 1023) / 1024;
+  const int32_t b = tid * per, e = b + per < dim ? b + per : dim;
   uint32_t s = 0;
-  for (int32_t i = b; i < e; ++i) s += tp[i];
+  for (int32_t i = b; i < e; ++i) s += (sg[i].y + kSegAlign - 1) / kSegAlign * kSegAlign;
   part[tid] = s;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {
@@ -244,9 +250,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *tile_ptr, int64_t 
   }
   uint32_t run = part[tid] - s;
   for (int32_t i = b; i < e; ++i) {
-    run += tp[i];
-    tp[i] = run;
+    const uint32_t len = sg[i].y;
+    sg[i] = make_uint2(run, 0u);
+    run += (len + kSegAlign - 1) / kSegAlign * kSegAlign;
   }
+  if (tid == 1023) tile_total[tile0 + blockIdx.x] = part[1023];
 }
 
 __global__ void k_tile_scatter(BuildArgs a) {
@@ -254,12 +262,13 @@ __global__ void k_tile_scatter(BuildArgs a) {
   const int lane = threadIdx.x % kWave;
   if (row >= a.row1) return;
   const int64_t tile = row / a.cb;
-  uint32_t *tp = a.tile_ptr + tile * a.tp_stride;
-  Posting *post = a.post + a.rowptr[tile * a.cb];
+  uint2 *sg = a.tile_seg + tile * a.seg_stride;
+  Posting *post = a.post + a.tile_post_base[tile];
   const uint32_t local = (uint32_t)(row - tile * a.cb);
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
   for (int64_t k = b + lane; k < e; k += kWave) {
-    const uint32_t pos = atomicAdd(&tp[a.idx[k] + 1], 1u);
+    const int32_t t = a.idx[k];
+    const uint32_t pos = sg[t].x + atomicAdd(&sg[t].y, 1u);
     Posting p;
     p.slot = local;
     p.w = a.val[k];
@@ -291,10 +300,10 @@ __global__ void k_tile_min_sub(const float *sub, int64_t n_rows, int32_t cb, flo
 
 struct ProbeArgs {
   // index
-  const uint32_t *tile_ptr;
-  int64_t tp_stride;
+  const uint2 *tile_seg;          // [n_tiles][seg_stride] {first posting, length} per term
+  int64_t seg_stride;
   const Posting *post;
-  const int64_t *store_rowptr;  // tile T's postings start at post[store_rowptr[T * cb]]
+  const int64_t *tile_post_base;  // [n_tiles + 1] tile T's postings are post[base[T] .. base[T + 1])
   const int64_t *ext_id;        // candidate external ids
   const float *c_scale;         // shard sub-norm per candidate slot (null: 1)
   const float *tile_scale;      // min positive sub-norm per tile (null: 1)
@@ -376,9 +385,9 @@ __global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
   const int chunk = blockIdx.x % a.n_chunks;
   const int q0 = chunk * a.q_chunk;
   const int q1 = min(a.nq, q0 + a.q_chunk);
-  const uint32_t *tp = a.tile_ptr + (int64_t)tile * a.tp_stride;
+  const uint2 *tp = a.tile_seg + (int64_t)tile * a.seg_stride;
   const int64_t tile_row0 = (int64_t)tile * cb;
-  const Posting *post = a.post + a.store_rowptr[tile_row0];
+  const Posting *post = a.post + a.tile_post_base[tile];
   const float tile_scale = a.tile_scale ? a.tile_scale[tile] : 1.0f;
 
   if (tid < 8) L.ctr[tid] = 0;
@@ -401,8 +410,9 @@ __global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
     if (qb0 + tid < qe0) {
       const int32_t t = a.q_idx[qb0 + tid];
       w0 = a.q_val[qb0 + tid];
-      s0 = tp[t];
-      len0 = tp[t + 1] - s0;
+      const uint2 sg = tp[t];
+      s0 = sg.x;
+      len0 = sg.y;
     }
     if (q0 + 1 < q1) {
       qb1 = a.q_rowptr[q0 + 1];
@@ -428,8 +438,9 @@ __global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
     // ---- issue the next rounds' loads: P(r+1), I(r+2), R(r+3) ----
     uint32_t s1 = 0, len1 = 0;
     if (q + 1 < q1 && qb1 + tid < qe1) {
-      s1 = tp[term1];
-      len1 = tp[term1 + 1] - s1;
+      const uint2 sg = tp[term1];
+      s1 = sg.x;
+      len1 = sg.y;
     }
     int32_t term2 = 0;
     float w2 = 0.f;
@@ -464,8 +475,9 @@ __global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
         if (t0 + tid < nnz) {
           const int32_t t = a.q_idx[qb + t0 + tid];
           w = a.q_val[qb + t0 + tid];
-          s = tp[t];
-          len = tp[t + 1] - s;
+          const uint2 sg = tp[t];
+          s = sg.x;
+          len = sg.y;
         }
       }
       my_visits += len;
@@ -664,12 +676,12 @@ __host__ __device__ inline size_t probe_wave_lds_bytes(int cb, int block, int u,
 
 // inclusive prefix sum over the 64 lanes with DPP (VALU only, no LDS round trips)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1, lanes without a source add 0
+  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2, 3
   return x;
 }
 
@@ -677,7 +689,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 // crossings per round kept in LDS (more: the round falls back to scanning the accumulators)
 typedef unsigned int apss_u32x2 __attribute__((ext_vector_type(2)));
 
-template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool DIAG = false>
+template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, bool DIAG = false>
 __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   constexpr int GPW = kWave / kChunk;  // chunk groups per wave step (8)
@@ -702,8 +714,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   const int q0 = chunk * a.q_chunk;
   const int q1 = min(a.nq, q0 + a.q_chunk);
   const int64_t tile_row0 = (int64_t)tile * cb;
-  const int64_t tile_row1 = min(tile_row0 + cb, a.n_rows);
-  const float tile_scale = a.tile_scale ? a.tile_scale[tile] : 1.0f;
+  const float tile_scale = SHARD ? a.tile_scale[tile] : 1.0f;
   const int kterm = ln * NW + wv;               // the term of the query this lane looks after
   const uint32_t lo = (uint32_t)(ln % kChunk);  // posting of the chunk this lane handles
   uint2 *wl = items + wv * WIN;                 // this wave's chunk strip
@@ -712,13 +723,13 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   // buffer descriptors built from wave-uniform values only (32-bit offsets, hardware range check: a read past
   // the end returns 0, which is what makes every load below unconditional and every address clamp-free)
   const int64_t qbase = a.q_rowptr[q0], qend = a.q_rowptr[q1];
-  const int64_t pbase = a.store_rowptr[tile_row0], pend = a.store_rowptr[tile_row1];
+  const int64_t pbase = a.tile_post_base[tile], pend = a.tile_post_base[tile + 1];
   const __amdgpu_buffer_rsrc_t rs_qi =
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_idx + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_qv =
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_val + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_tp = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(a.tile_ptr + (int64_t)tile * a.tp_stride), 0, (int)(a.tp_stride * 4), 0x00020000);
+      (void *)(a.tile_seg + (int64_t)tile * a.seg_stride), 0, (int)(a.seg_stride * 8), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_po =
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.post + pbase), 0, (int)((pend - pbase) * 8), 0x00020000);
   constexpr uint32_t kOob = 0xfffffff0u;  // an offset no descriptor covers
@@ -758,9 +769,9 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   };
   auto load_P = [&](const TermW &t) {
     Seg g;
-    const apss_u32x2 be = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, t.term * 4u, 0, 0);  // {tp[term], tp[term + 1]}
-    g.s = be.x;
-    g.len = t.valid ? be.y - be.x : 0u;
+    const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, t.term * 8u, 0, 0);  // {first posting, length}
+    g.s = sg.x;
+    g.len = t.valid ? sg.y : 0u;
     g.w = t.w;
     return g;
   };
@@ -799,13 +810,16 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
     put(2);
     if (__any(nch > 3u))  // rare: a segment of more than 24 postings in a 16384-row tile
       for (uint32_t k = 3; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
+    uint2 it[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) it[u] = wl[u * GPW + ln / kChunk];  // all reads in flight before the first use
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(it[u].x), "+v"(it[u].y));  // whole ds_read_b64s, no branch around half
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      uint2 it = wl[u * GPW + ln / kChunk];
-      asm volatile("" : "+v"(it.x), "+v"(it.y));                     // one ds_read_b64, not a branch around half of it
-      const uint32_t c1 = it.x & 7u;                                  // postings in the chunk - 1
-      f.wq[u] = lo <= c1 ? __uint_as_float(it.y) : 0.0f;             // 0 marks the lanes past the chunk's end
-      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (it.x ^ c1) + lo * 8u, 0, 0);
+      const uint32_t c1 = it[u].x & 7u;                               // postings in the chunk - 1
+      f.wq[u] = lo <= c1 ? __uint_as_float(it[u].y) : 0.0f;          // 0 marks the lanes past the chunk's end
+      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (it[u].x ^ c1) + lo * 8u, 0, 0);
     }
   };
 
@@ -839,10 +853,10 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   auto round = [&](WaveWork &w0, WaveWork &w2, const int q, const int l3) {
     unsigned long long tprev = DIAG ? clock64() : 0;
     const int par = (q - q0) & 1;
-    const float qs = a.q_scale ? a.q_scale[q] : 1.0f;
+    const float qs = SHARD ? a.q_scale[q] : 1.0f;
     const float thr = a.theta * qs * tile_scale;
     // shard mode: the candidate test is a necessary condition that is verified exactly later, so round it down
-    const uint32_t thr_fx = (a.q_scale || a.tile_scale) ? (uint32_t)(thr * fxs * 0.999999f) : a.theta_fx;
+    const uint32_t thr_fx = SHARD ? max(1u, (uint32_t)(thr * fxs * 0.999999f)) : a.theta_fx;
     const uint32_t thr1 = thr_fx - 1u;  // theta > 0 => thr_fx >= 1
 
     // ---- stage loads for the rounds ahead ----
@@ -876,10 +890,15 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
         old[u] = 1u;
         if (w0.wq[u] != 0.0f) old[u] = atomicAdd(&acc[w0.pc[u].x], p[u]);  // ds_add_rtn_u32
       }
+      bool any_cross = false;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         my_cands += old[u] == 0u ? 1u : 0u;  // first touch of this candidate in this round
-        if (w0.wq[u] != 0.0f) crossed(w0.pc[u].x, p[u], old[u]);
+        any_cross |= thr1 - old[u] < p[u];    // idle lanes: old = 1, p = 0: never true
+      }
+      if (any_cross) {  // rare: some add of this lane took a candidate across the threshold
+#pragma unroll
+        for (int u = 0; u < U; ++u) crossed(w0.pc[u].x, p[u], old[u]);
       }
     }
     APSS_STAMP(1)
@@ -941,7 +960,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
             c = surv[i];
             sc = (float)acc[c] * fxinv;
             const int64_t gs = tile_row0 + c;
-            ok = a.ext_id[gs] != qext && (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs] * 0.999999f);
+            ok = a.ext_id[gs] != qext && (!SHARD || sc >= a.theta * qs * a.c_scale[gs] * 0.999999f);
           }
           const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
           if (ok && o < a.res_cap) {
@@ -959,7 +978,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
             sc = (float)raw * fxinv;
             const int64_t gs = tile_row0 + i;
             ok = raw >= thr_fx && gs < a.n_rows && a.ext_id[gs] != qext &&
-                 (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs] * 0.999999f);
+                 (!SHARD || sc >= a.theta * qs * a.c_scale[gs] * 0.999999f);
           }
           const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
           if (ok && o < a.res_cap) {
