@@ -65,7 +65,7 @@ def lib():
     L.apss_last_error.restype = C.c_char_p
     L.apss_last_error.argtypes = [vp]
     L.apss_set_stream.restype = i32
-    L.apss_set_stream.argtypes = [vp, vp]
+    L.apss_set_stream.argtypes = [vp, vp, i32]
     for name in ("apss_insert",):
         f = getattr(L, name)
         f.restype = i32

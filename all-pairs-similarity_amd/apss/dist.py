@@ -1,0 +1,194 @@
+"""Term-range-sharded self-join across the GPUs of one node (one process per GPU, torch.distributed = RCCL over xGMI).
+
+The reference shards its inverted index by term too (dim % maxShardNum, dim % maxIndexEntryActorNum:
+WriteWorkerActor.scala:172-175, EntryProxyActor.scala:41-46) but replicates every full vector to every shard and
+lets each worker recompute the whole dot product (SparseVectorWrapper.scala:9).  Here shard g owns a contiguous
+term RANGE, stores only that slice of every vector, and the exact score is assembled from per-shard partials:
+
+  1. local (no communication): shard g probes its slice and keeps the CANDIDATES, pairs whose partial p_g satisfies
+     p_g >= theta * |q_g| * |c_g|  (|x_g| = L2 norm of x restricted to g's terms).  If sum_g p_g >= theta then, since
+     p_g <= |q_g||c_g| and sum_g |q_g||c_g| <= |q||c| <= 1 (Cauchy-Schwarz twice, unit-norm inputs), at least one
+     shard passes the test: no true pair is lost, and random pairs (one shared term) almost never pass.
+  2. all-gather of the candidate lists (a few MB at most), union;
+  3. every shard computes its exact partial for every candidate (apss_partial_scores_dev);
+  4. ONE all-reduce(SUM) of the per-candidate partial scores over RCCL, then the `>= theta` prune (IWA:93).
+
+A dense all-reduce of per-query accumulators would move 4*N bytes per query (~50x slower than
+the single-GPU join); this exchange moves O(#near-pairs).  Requires ||x|| <= 1 (the reference's own precondition:
+CommonUtils.scala:88 "assuming the normalized vectors").
+
+The compute engine is injected so the host logic can be exercised on CPU with gloo in tests (tests/ provides an
+engine backed by the CPU oracle); the product engine below is HIP-only.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def term_ranges(df, world):
+    """Cut [0, dim) into `world` contiguous ranges with (nearly) equal sum of df^2 (= posting visits of a self-join)."""
+    w = df.astype(np.float64) ** 2
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1]
+    cuts = [0]
+    for g in range(1, world):
+        cuts.append(int(np.searchsorted(cum, total * g / world)))
+    cuts.append(len(df))
+    for g in range(1, world + 1):  # strictly increasing, non-empty
+        cuts[g] = max(cuts[g], cuts[g - 1] + 1)
+    cuts[-1] = len(df)
+    return [(cuts[g], cuts[g + 1]) for g in range(world)]
+
+
+class HipShardEngine:
+    """One shard resident on one MI355X (libapss_hip.so through the C ABI; no fallback): the postings of the terms in
+    `term_range` for the candidate rows in `row_range`.  Queries are always all rows of the batch."""
+
+    def __init__(self, dim, theta, term_range, device, tile_rows=0):
+        from .engine import ApssIndex
+        self.device = device
+        self.ix = ApssIndex(dim, theta, device=device.index or 0, tile_rows=tile_rows, term_range=term_range)
+        # run on torch's stream: the tensors handed to the library are produced by torch kernels on that stream
+        self.ix.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def load(self, rp, idx, val, row_range=None):
+        dev = self.device
+        self.n = len(rp) - 1
+        self.r0, self.r1 = (0, self.n) if row_range is None else row_range
+        self.d_rp = torch.from_numpy(rp).to(dev)
+        self.d_idx = torch.from_numpy(idx).to(dev)
+        self.d_val = torch.from_numpy(val.astype(np.float32)).to(dev)
+        self.d_ids = torch.arange(self.n, dtype=torch.int64, device=dev)
+        self.whole = (self.r0, self.r1) == (0, self.n)
+        if not self.whole:  # the candidate rows of this shard as their own CSR batch
+            e0, e1 = int(rp[self.r0]), int(rp[self.r1])
+            self.s_rp = (self.d_rp[self.r0:self.r1 + 1] - e0).contiguous()
+            self.s_idx = self.d_idx[e0:e1].contiguous()
+            self.s_val = self.d_val[e0:e1].contiguous()
+            self.s_ids = self.d_ids[self.r0:self.r1].contiguous()
+        torch.cuda.synchronize()
+
+    def candidates(self):
+        """phase 1: rebuild the shard's index and return its candidate pairs (query row, candidate row), global rows"""
+        self.ix.clear()
+        if self.whole:
+            self.ix.insert_and_query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
+        else:
+            self.ix.insert_dev(self.s_ids, self.s_rp, self.s_idx, self.s_val)
+            self.ix.query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
+        q, c, _ = self.ix.fetch()  # external ids == global row numbers
+        self.stats = self.ix.stats()
+        return (torch.from_numpy(q).to(self.device), torch.from_numpy(c).to(self.device))
+
+    def partial(self, q_row, c_row):
+        out = torch.empty(q_row.numel(), dtype=torch.float32, device=self.device)
+        if q_row.numel():
+            qi = q_row.to(torch.int32).contiguous()
+            ci = (c_row - self.r0).to(torch.int32).contiguous()  # candidate slot inside this shard
+            self.ix.partial_scores_dev(qi, ci, out)  # same stream as the conversions above (set_stream in __init__)
+        return out
+
+
+def join_shards_local(engines, n, theta):
+    """The same four phases with every shard in ONE process (no collectives): used to test the shard kernels and the
+    candidate rule on a single GPU.  Returns (q_rows, c_slots, scores) of the pairs >= theta."""
+    keys = []
+    for e in engines:
+        q, c = e.candidates()
+        keys.append(q.to(torch.int64) * n + c.to(torch.int64))
+    uniq = torch.unique(torch.cat(keys))
+    uq = torch.div(uniq, n, rounding_mode="floor")
+    uc = uniq - uq * n
+    total = None
+    for e in engines:
+        p = e.partial(uq, uc)
+        total = p if total is None else total + p
+    keep = total >= theta
+    return uq[keep].cpu().numpy(), uc[keep].cpu().numpy(), total[keep].cpu().numpy(), [int(k.numel()) for k in keys]
+
+
+class ShardedJoin:
+    """world = T x D ranks: rank r owns term range (r % T) of the candidate rows in row range (r // T).
+
+    T term shards share a candidate range and combine their partial scores with an all-reduce inside their group
+    (the exchange the term-sharded index needs); the D candidate ranges are independent (their result sets are
+    disjoint).  Term shards alone do not speed the join up much: a shard has 1/T of the posting visits of every
+    (query, tile) round but the same number of rounds, and the per-round cost is mostly fixed -- so by
+    default T = 2 whenever world >= 2 and the remaining factor goes to candidate ranges."""
+
+    def __init__(self, dim, theta, rank, world, device, tile_rows=0, engine_factory=None, comm_device=None,
+                 term_shards=None):
+        self.dim, self.theta, self.rank, self.world, self.device = dim, float(theta), rank, world, device
+        # collectives run on `comm_device` tensors: the GPU itself under RCCL, the CPU when rehearsing with gloo
+        self.comm = comm_device or device
+        self.tile_rows = tile_rows
+        T = term_shards or (2 if world % 2 == 0 else 1)
+        if world % T:
+            raise ValueError("term_shards must divide the world size")
+        self.T, self.D = T, world // T
+        self.ti, self.dj = rank % T, rank // T
+        self.group = None
+        if world > 1 and T > 1 and self.D > 1:  # every rank creates every group, in the same order
+            for j in range(self.D):
+                g = dist.new_group([j * T + i for i in range(T)])
+                if j == self.dj:
+                    self.group = g
+        self.engine_factory = engine_factory or (lambda tr: HipShardEngine(dim, theta, tr, device, tile_rows))
+        self.last = {}
+
+    def load(self, rp, idx, val):
+        """every rank holds the same batch (same seed / same broadcast); each indexes only its terms x rows"""
+        df = np.bincount(idx, minlength=self.dim)
+        self.ranges = term_ranges(df, self.T)
+        self.term_range = self.ranges[self.ti]
+        self.n = len(rp) - 1
+        self.row_range = (self.n * self.dj // self.D, self.n * (self.dj + 1) // self.D)
+        self.engine = self.engine_factory(self.term_range)
+        self.engine.load(rp, idx, val, None if self.D == 1 else self.row_range)
+
+    def _all_gather_var(self, t):
+        """all-gather (inside the term group) of 1-D int64 tensors of different lengths"""
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=self.comm)
+        sizes = [torch.zeros_like(n) for _ in range(self.T)]
+        dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        m = max(sizes + [1])
+        buf = torch.zeros(m, dtype=torch.int64, device=self.comm)
+        buf[: t.numel()] = t.to(self.comm)
+        out = [torch.empty_like(buf) for _ in range(self.T)]
+        dist.all_gather(out, buf, group=self.group)
+        return torch.cat([o[:s] for o, s in zip(out, sizes)]).to(self.device), sizes
+
+    def step(self, return_pairs=False):
+        q, c = self.engine.candidates()
+        key = q.to(torch.int64) * self.n + c.to(torch.int64)
+        if self.T > 1:
+            allk, sizes = self._all_gather_var(key)
+        else:
+            allk, sizes = key, [key.numel()]
+        uniq = torch.unique(allk)  # sorted: every rank of the group sees the same order
+        uq = torch.div(uniq, self.n, rounding_mode="floor")
+        uc = uniq - uq * self.n
+        part = self.engine.partial(uq, uc)
+        if self.T > 1:
+            part = part.to(self.comm)
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)  # RCCL all-reduce of partial scores
+            part = part.to(self.device)
+        keep = part >= self.theta
+        st = getattr(self.engine, "stats", {}) or {}
+        # whole-job counters: posting visits and touched pairs add up over all ranks; result pairs over the D groups
+        mine = float(keep.sum().item()) if self.ti == 0 else 0.0
+        tot = torch.tensor([float(st.get("posting_visits", 0)), float(st.get("candidate_pairs", 0)), mine],
+                           dtype=torch.float64, device=self.comm)
+        if self.world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        self.last = {
+            "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0),
+            "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
+            "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes,
+                         "union": int(uniq.numel()), "all_gather_bytes_per_rank": 8 * max(sizes + [1]) * self.T,
+                         "all_reduce_bytes": 4 * int(uniq.numel()), "term_ranges": self.ranges},
+        }
+        if return_pairs:  # this rank's group result (the whole result when D == 1)
+            return uq[keep].cpu().numpy(), uc[keep].cpu().numpy(), part[keep].cpu().numpy()
+        return int(tot[2].item())

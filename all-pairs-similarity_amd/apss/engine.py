@@ -127,7 +127,11 @@ class ApssIndex:
 
     # -- device-pointer path (torch tensors on this handle's GPU; torch is plumbing only)
     def set_stream(self, cuda_stream_handle):
-        self._chk(self._L.apss_set_stream(self._h, C.c_void_p(cuda_stream_handle)))
+        """run on this HIP stream (0 = the default stream, where torch works unless told otherwise)"""
+        self._chk(self._L.apss_set_stream(self._h, C.c_void_p(cuda_stream_handle), 0))
+
+    def use_own_stream(self):
+        self._chk(self._L.apss_set_stream(self._h, C.c_void_p(0), 1))
 
     @staticmethod
     def _dev(rowptr, indices, values, ids):

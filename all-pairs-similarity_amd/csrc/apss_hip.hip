@@ -159,6 +159,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
 
   IngestArgs a{};
   a.n = n;
+  a.nnz = nnz;
   a.rowptr = d_rowptr;
   a.idx = d_idx;
   a.val = d_val;
@@ -575,7 +576,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
     delete h;
     return APSS_E_DEVICE;
   }
-  if ((e = hipSetDevice(h->dev)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+  if ((e = hipSetDevice(h->dev)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault)) != hipSuccess ||
       (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
     g_create_error = std::string("HIP init failed: ") + hipGetErrorString(e);
     delete h;
@@ -621,10 +622,10 @@ void apss_destroy(apss_handle *h) {
 
 const char *apss_last_error(const apss_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int32_t apss_set_stream(apss_handle *h, void *hip_stream) {
+int32_t apss_set_stream(apss_handle *h, void *hip_stream, int32_t use_own) {
   APSS_TRY(enter(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  h->stream = use_own ? h->own_stream : (hipStream_t)hip_stream;  // NULL is the device's default stream
   return APSS_OK;
 }
 
@@ -794,6 +795,8 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
   a.c_idx = h->idx.p;
   a.c_val = h->val.p;
   a.out = d_out_partial;
+  a.nq = h->last_nq;
+  a.n_rows = h->n_rows;
   hipLaunchKernelGGL(k_partial_scores, dim3((unsigned)ceil_div(n_pairs * kGroup, 256)), dim3(256), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -54,6 +54,7 @@ __device__ __forceinline__ uint64_t wave_append(bool pred, unsigned long long *c
 
 struct IngestArgs {
   int64_t n;
+  int64_t nnz;            // elements in idx / val: row extents outside [0, nnz] are rejected, never dereferenced
   const int64_t *rowptr;  // [n+1], relative to the batch
   const int32_t *idx;
   const float *val;
@@ -73,9 +74,12 @@ __global__ void k_ingest_count(IngestArgs a) {
   const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
   const int gl = threadIdx.x % kGroup;
   if (row >= a.n) return;
-  const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
+  int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
   unsigned bad = 0;
-  if (e < b) bad |= 1;
+  if (b < 0 || e < b || e > a.nnz) {  // malformed extents: flag the batch and read nothing
+    bad |= 1;
+    b = e = 0;
+  }
   float sumsq = 0.f;
   for (int64_t k = b + gl; k < e; k += kGroup) {
     const float v = a.val[k];
@@ -1055,14 +1059,20 @@ struct PartialArgs {
   const int32_t *c_idx;
   const float *c_val;
   float *out;
+  int64_t nq, n_rows;  // bounds of q_row / c_slot: a pair outside them scores 0 instead of faulting
 };
 
 __global__ void k_partial_scores(PartialArgs a) {
   const int64_t pair = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
   const int gl = threadIdx.x % kGroup;
   if (pair >= a.n_pairs) return;
-  const int64_t qb = a.q_rowptr[a.q_row[pair]], qe = a.q_rowptr[a.q_row[pair] + 1];
-  const int64_t cb = a.c_rowptr[a.c_slot[pair]], ce = a.c_rowptr[a.c_slot[pair] + 1];
+  const int64_t qr = a.q_row[pair], cs = a.c_slot[pair];
+  if (qr < 0 || qr >= a.nq || cs < 0 || cs >= a.n_rows) {  // caller error: never turn it into a wild read
+    if (gl == 0) a.out[pair] = 0.f;
+    return;
+  }
+  const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
+  const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
   float s = 0.f;
   for (int64_t k = qb + gl; k < qe; k += kGroup) {
     const int32_t t = a.q_idx[k];

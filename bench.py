@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--n", type=int, default=None, help="override the number of vectors (debug)")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid (default 2 when --gpus is even)")
+    ap.add_argument("--solo", default=None, help="T,D,i,j: time shard (term i of T, rows j of D) alone on this GPU (projection)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real run) | gloo (rehearsal: all ranks share GPU 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the baseline sample")
     return ap.parse_args()
 
@@ -76,10 +79,16 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    if a.backend == "gloo":
+        local_rank = 0  # rehearsal on a one-GPU box: every rank drives GPU 0, collectives on CPU tensors
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = torch.device("cpu") if a.backend == "gloo" else dev
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     cfg = dict(synth.CONFIGS[a.workload])
     if a.n:
@@ -95,6 +104,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if a.solo:
+        from apss.dist import HipShardEngine, term_ranges
+        T, D, ti, dj = (int(x) for x in a.solo.split(","))
+        tr = term_ranges(np.bincount(idx, minlength=cfg["dim"]), T)[ti]
+        eng = HipShardEngine(cfg["dim"], cfg["theta"], tr, dev, a.tile_rows)
+        eng.load(rp, idx, val, None if D == 1 else (n * dj // D, n * (dj + 1) // D))
+        eng.candidates()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            q, c = eng.candidates()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(json.dumps({"solo_shard": a.solo, "ms_per_step": dt * 1e3, "probe_kernel_ms": eng.stats["probe_ms"],
+                          "build_ms": eng.stats["build_ms"], "posting_visits": eng.stats["posting_visits"],
+                          "candidates": int(q.numel())}))
+        return
     if world == 1:
         d_rp = torch.from_numpy(rp).to(dev)
         d_idx = torch.from_numpy(idx).to(dev)
@@ -126,7 +152,21 @@ def main():
         extra = {}
     else:
         from apss.dist import ShardedJoin
-        sj = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows)
+        # distinct scored candidate pairs of the workload (a pair sharing terms in k shards is touched by k shards):
+        # counted once, untimed, by a plain single-GPU join on rank 0
+        distinct = torch.zeros(1, dtype=torch.float64, device=comm_dev)
+        if rank == 0:
+            ix0 = ApssIndex(cfg["dim"], cfg["theta"], device=local_rank, tile_rows=a.tile_rows)
+            ix0.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            ix0.insert_and_query_dev(torch.arange(n, dtype=torch.int64, device=dev), torch.from_numpy(rp).to(dev),
+                                     torch.from_numpy(idx).to(dev), torch.from_numpy(val.astype(np.float32)).to(dev))
+            distinct[0] = float(ix0.stats()["candidate_pairs"])
+            ix0.close()
+            del ix0
+            torch.cuda.empty_cache()
+        dist.all_reduce(distinct)
+        sj = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev,
+                         term_shards=a.term_shards)
         sj.load(rp, idx, val)
         probe_ms, build_ms = [], []
         for _ in range(a.warmup):
@@ -139,12 +179,17 @@ def main():
             build_ms.append(sj.last["build_ms"])
         sync()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        visits, cands, launches = sj.last["posting_visits"], sj.last["candidate_pairs"], 1
-        parallelism = "term-range shards x%d, candidate all-gather + RCCL all-reduce of partial scores" % world
-        extra = {"exchange": sj.last.get("exchange")}
+        pm = torch.tensor([float(np.mean(probe_ms))], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+        probe_ms = [float(pm.item())]  # slowest shard's probe kernel
+        visits, cands, launches = sj.last["posting_visits"], int(distinct.item()), world
+        parallelism = ("%d term-range shards x %d candidate ranges; per term group: candidate all-gather + RCCL "
+                       "all-reduce of partial scores" % (sj.T, sj.D))
+        extra = {"exchange": sj.last.get("exchange"), "shard_touched_pairs_sum": sj.last["candidate_pairs"],
+                 "backend": a.backend}
 
     if rank != 0:
         if world > 1:

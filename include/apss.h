@@ -86,8 +86,10 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out);
 void apss_destroy(apss_handle *h);
 /* message of the last failing call on this handle ("" if none); h == NULL: last apss_create failure */
 const char *apss_last_error(const apss_handle *h);
-/* Use a caller-owned HIP stream (hipStream_t as void*) instead of the handle's own; NULL restores it. */
-int32_t apss_set_stream(apss_handle *h, void *hip_stream);
+/* Run the handle's work on a caller-owned HIP stream (hipStream_t as void*; NULL = the device's default stream),
+ * or, with use_own != 0, go back to the handle's own stream.  The handle's own stream is a blocking stream: it
+ * orders itself after work already queued on the default stream (where PyTorch runs unless told otherwise). */
+int32_t apss_set_stream(apss_handle *h, void *hip_stream, int32_t use_own);
 
 /* ---- host-pointer entry points (what the JNI shim binds) ----
  * CSR batch: n rows; row i = indices[rowptr[i] .. rowptr[i+1]) strictly increasing in [0, dim), values alike
