@@ -1,0 +1,179 @@
+// cpslab_host.cpp -- see cpslab_host.hpp.  Pure host code over the C ABI (include/apss.h); links libapss_hip.so.
+#include "cpslab_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <sstream>
+
+#include "../../include/apss.h"
+
+namespace cpslab {
+
+SparseVector::SparseVector(int size_, std::vector<int32_t> idx, std::vector<double> val)
+    : size(size_), indices(std::move(idx)), values(std::move(val)) {
+  if (indices.size() != values.size()) throw std::invalid_argument("requirement failed");  // SparseVector.scala:202
+}
+
+std::string SparseVector::toString() const {
+  std::ostringstream o;
+  o.precision(17);
+  o << "(" << size << ",[";
+  for (size_t i = 0; i < indices.size(); ++i) o << (i ? "," : "") << indices[i];
+  o << "],[";
+  for (size_t i = 0; i < values.size(); ++i) o << (i ? "," : "") << values[i];
+  o << "])";
+  return o.str();
+}
+
+SparseVector SparseVector::fromString(const std::string &s) {
+  // inputString.split(",\\[") must give 3 pieces (SparseVector.scala:133-136)
+  const size_t p1 = s.find(",[");
+  const size_t p2 = p1 == std::string::npos ? p1 : s.find(",[", p1 + 2);
+  if (p1 == std::string::npos || p2 == std::string::npos || s.find(",[", p2 + 2) != std::string::npos)
+    throw std::runtime_error("cannot parse " + s);
+  auto strip = [](std::string t, const char *drop) {
+    for (const char *d = drop; *d; ++d) t.erase(std::remove(t.begin(), t.end(), *d), t.end());
+    return t;
+  };
+  SparseVector v;
+  v.size = std::stoi(strip(s.substr(0, p1), "("));
+  std::stringstream is(strip(s.substr(p1 + 2, p2 - p1 - 2), "]")), vs(strip(s.substr(p2 + 2), "])"));
+  std::string tok;
+  while (std::getline(is, tok, ',')) if (!tok.empty()) v.indices.push_back(std::stoi(tok));
+  while (std::getline(vs, tok, ',')) if (!tok.empty()) v.values.push_back(std::stod(tok));
+  if (v.indices.size() != v.values.size()) throw std::invalid_argument("requirement failed");
+  return v;
+}
+
+std::string SimilarityOutput::toString() const {  // Message.scala:23-34
+  std::ostringstream o;
+  for (const auto &q : output) {
+    o << "---------------------------------" << q.first << ":";
+    for (const auto &c : q.second) o << c.first << "," << c.second << ";";
+    o << "\n";
+  }
+  return o.str();
+}
+
+static int64_t now_ms() {
+  return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+GpuIndexingWorker::GpuIndexingWorker(const Config &conf, ReplyTo replyTo) : conf_(conf), reply_to_(std::move(replyTo)) {
+  apss_config c{};
+  c.struct_size = (int32_t)sizeof(c);
+  c.dim = conf.vectorDim;
+  c.theta = conf.similarityThreshold;
+  c.index_threshold = conf.indexThreshold;
+  c.flags = conf.applyIndexThreshold ? APSS_FLAG_VALUE_PRUNE : 0u;
+  c.device_id = conf.deviceId;
+  c.tile_rows = conf.tileRows;
+  const int32_t rc = apss_create(&c, &h_);
+  if (rc != APSS_OK) throw std::runtime_error(std::string("apss_create: ") + apss_last_error(nullptr));
+}
+
+GpuIndexingWorker::~GpuIndexingWorker() { apss_destroy(h_); }
+
+int64_t GpuIndexingWorker::storedVectors() const {
+  int64_t rows = 0;
+  apss_size(h_, &rows, nullptr);
+  return rows;
+}
+
+SimilarityOutput GpuIndexingWorker::handle(const IndexData &m) {
+  // flatten the batch to CSR; every vector's size must equal vectorDim (the require of CommonUtils.scala:99)
+  std::vector<int64_t> rowptr{0}, ids;
+  std::vector<int32_t> idx;
+  std::vector<double> val;
+  for (const auto &kv : m.vectors) {
+    const SparseVector &v = kv.second;
+    if (v.size != conf_.vectorDim)
+      throw std::invalid_argument("requirement failed: vector1 size: " + std::to_string(v.size) + ", vector2 size: " +
+                                  std::to_string(conf_.vectorDim));
+    auto it = id_of_.find(kv.first);
+    if (it == id_of_.end()) {
+      it = id_of_.emplace(kv.first, (int64_t)name_of_.size()).first;
+      name_of_.push_back(kv.first);
+    }
+    ids.push_back(it->second);
+    idx.insert(idx.end(), v.indices.begin(), v.indices.end());
+    val.insert(val.end(), v.values.begin(), v.values.end());
+    rowptr.push_back((int64_t)idx.size());
+  }
+  int64_t n_res = 0;
+  const int64_t n = (int64_t)ids.size();
+  const int32_t rc = stop_update_index_  // IndexingWorkerActor.scala:125-133
+                         ? apss_query(h_, n, rowptr.data(), idx.data(), val.data(), ids.data(), &n_res)
+                         : apss_insert_and_query(h_, n, rowptr.data(), idx.data(), val.data(), ids.data(), &n_res);
+  if (rc != APSS_OK) throw std::runtime_error(apss_last_error(h_));
+  std::vector<int64_t> q((size_t)n_res), c((size_t)n_res);
+  std::vector<float> s((size_t)n_res);
+  if (n_res && apss_fetch_results(h_, 0, n_res, q.data(), c.data(), s.data()) != APSS_OK)
+    throw std::runtime_error(apss_last_error(h_));
+  SimilarityOutput out;
+  for (const auto &kv : m.vectors) out.output[kv.first];  // every query gets an entry, possibly empty (:106-107)
+  for (int64_t i = 0; i < n_res; ++i) out.output[name_of_[(size_t)q[i]]][name_of_[(size_t)c[i]]] = (double)s[i];
+  out.outputMoment = now_ms();
+  return out;
+}
+
+void GpuIndexingWorker::receive(const IndexData &m) {
+  try {
+    SimilarityOutput out = handle(m);
+    if (!reply_to_) return;
+    if (conf_.outputIODuration <= 0) {
+      reply_to_(out);  // replyTo.get ! SimilarityOutput(...), :130
+    } else {           // updateWriteBuffer, :113-120
+      for (auto &q : out.output)
+        for (auto &c : q.second) write_buffer_[q.first][c.first] = c.second;
+    }
+  } catch (const std::exception &e) {  // case e: Exception => e.printStackTrace(), :135-137: the batch's output is lost
+    last_error_ = e.what();
+    std::fprintf(stderr, "GpuIndexingWorker: %s\n", e.what());
+  }
+}
+
+void GpuIndexingWorker::receive(const IOTicket &) {
+  if (write_buffer_.empty()) return;
+  SimilarityOutput out;
+  out.output = write_buffer_;  // writeBuffer.clone()
+  out.outputMoment = now_ms();
+  write_buffer_.clear();
+  if (reply_to_) reply_to_(out);
+}
+
+void GpuIndexingWorker::receive(const Test &t) {
+  std::printf("receiving Test(%s) in IndexWorkerActor\n", t.content.c_str());
+}
+
+void GpuIndexingWorker::receiveTimeout() { stop_update_index_ = true; }
+
+void Region::tell(const VectorIOMsg &m) {
+  IndexData d;
+  d.vectors = m.vectors;
+  worker_->receive(d);
+}
+
+ClientConnection::ClientConnection(const std::vector<std::string> &remoteAddresses,
+                                   std::function<std::shared_ptr<Region>(const std::string &)> resolve) {
+  for (const std::string &hp : remoteAddresses) {  // ClientConnection.scala:12-21
+    const size_t colon = hp.find(':');
+    if (colon == std::string::npos) throw std::out_of_range("ArrayIndexOutOfBoundsException: 1");  // hostAndPort(1)
+    routers_.push_back("akka.tcp://ClusterSystem@" + hp.substr(0, colon) + ":" + hp.substr(colon + 1) + "/user/regionRouter");
+  }
+  if (routers_.empty()) throw std::invalid_argument("bound must be positive");  // Random.nextInt(0)
+  std::mt19937 rng{std::random_device{}()};
+  remote_router_ = resolve(routers_[rng() % routers_.size()]);  // Random.nextInt(remoteAddresses.length), :23-24
+}
+
+void ClientConnection::insertNewVector(const std::vector<std::pair<std::string, SparkSparseVector>> &vectors) {
+  VectorIOMsg m;
+  m.vectors = vectors;
+  if (remote_router_) remote_router_->tell(m);  // remoteRouter ! VectorIOMsg(vectors)
+}
+
+}  // namespace cpslab

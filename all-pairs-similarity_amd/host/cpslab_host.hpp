@@ -1,0 +1,111 @@
+// cpslab_host.hpp -- C++ mirror of the reference's host-side interface for the hot path, above the C ABI.
+//
+// The reference is Scala on the JVM and no JDK exists in this image, so the classes a user of the reference touches
+// on this path are mirrored here in C++ with the same names, argument meaning and error behaviour (the Scala/JNI
+// originals a maintainer would actually deploy are under ../jvm/):
+//   cpslab::SparseVector           core/src/main/scala/cpslab/vector/SparseVector.scala:198-223 (+ parser :132-141)
+//   cpslab::VectorIOMsg/IndexData/SimilarityOutput/Test/IOTicket   .../message/Message.scala:13-43
+//   cpslab::GpuIndexingWorker      .../deploy/server/IndexingWorkerActor.scala:21-148 with the index on the GPU
+//   cpslab::ClientConnection       .../deploy/client/ClientConnection.scala:10-33
+// Akka itself (remoting, sharding, routers) is out of scope: "actors" are plain objects, `!` is a direct call.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+struct apss_handle;
+
+namespace cpslab {
+
+// SparseVector(size, indices, values); `require(indices.length == values.length)` (SparseVector.scala:202)
+struct SparseVector {
+  int size = 0;
+  std::vector<int32_t> indices;
+  std::vector<double> values;
+  SparseVector() = default;
+  SparseVector(int size_, std::vector<int32_t> idx, std::vector<double> val);
+  std::string toString() const;                          // "(size,[i,...],[v,...])", SparseVector.scala:204-205
+  static SparseVector fromString(const std::string &s);  // Vectors.fromString, SparseVector.scala:132-141
+};
+using SparkSparseVector = SparseVector;  // org.apache.spark.mllib.linalg.SparseVector is used as the same struct
+
+struct VectorIOMsg { std::vector<std::pair<std::string, SparkSparseVector>> vectors; };  // Message.scala:13
+struct IndexData { std::vector<std::pair<std::string, SparseVector>> vectors; };         // Message.scala:18 (wrappers' payload)
+struct Test { std::string content; };                                                    // Message.scala:37
+struct IOTicket {};                                                                      // Message.scala:39
+struct SimilarityOutput {                                                                // Message.scala:20-35
+  std::unordered_map<std::string, std::unordered_map<std::string, double>> output;
+  int64_t outputMoment = 0;  // System.currentTimeMillis
+  std::string toString() const;
+};
+
+// the cpslab.allpair.* keys the path reads (IndexingWorkerActor.scala:23-33, WriteWorkerActor.scala:35, EntryProxyActor.scala:25)
+struct Config {
+  double similarityThreshold = 0.0;
+  int vectorDim = 0;
+  int64_t outputIODuration = 0;   // <= 0: reply per batch; > 0: accumulate, flush on IOTicket
+  double indexThreshold = 0.0;
+  bool applyIndexThreshold = false;
+  int deviceId = 0;
+  int tileRows = 0;
+};
+
+// IndexingWorkerActor with vectorsStore / invertedIndex resident on the GPU.
+class GpuIndexingWorker {
+ public:
+  using ReplyTo = std::function<void(const SimilarityOutput &)>;  // the actor at cpslab.allpair.outputActor
+  GpuIndexingWorker(const Config &conf, ReplyTo replyTo);
+  ~GpuIndexingWorker();
+  GpuIndexingWorker(const GpuIndexingWorker &) = delete;
+  GpuIndexingWorker &operator=(const GpuIndexingWorker &) = delete;
+
+  void receive(const IndexData &m);  // IndexingWorkerActor.scala:123-137: exceptions are printed and swallowed
+  void receive(const IOTicket &);    // :138-142
+  void receive(const Test &t);       // :145-147 (echo)
+  void receiveTimeout();             // ReceiveTimeout -> stopUpdateIndex = true, :143-144
+  int64_t storedVectors() const;
+  const std::string &lastError() const { return last_error_; }
+
+ private:
+  SimilarityOutput handle(const IndexData &m);
+  Config conf_;
+  ReplyTo reply_to_;
+  apss_handle *h_ = nullptr;
+  bool stop_update_index_ = false;
+  std::unordered_map<std::string, int64_t> id_of_;  // String id <-> the ABI's int64 handle
+  std::vector<std::string> name_of_;
+  std::unordered_map<std::string, std::unordered_map<std::string, double>> write_buffer_;  // :27, 113-120
+  std::string last_error_;
+};
+
+// The region the client's router resolves to.  In the reference this is Akka remoting + cluster sharding +
+// EntryProxyActor/WriteWorkerActor fan-out (out of scope); here it hands the batch to one GPU worker.
+class Region {
+ public:
+  explicit Region(std::shared_ptr<GpuIndexingWorker> w) : worker_(std::move(w)) {}
+  void tell(const VectorIOMsg &m);
+ private:
+  std::shared_ptr<GpuIndexingWorker> worker_;
+};
+
+// class ClientConnection(remoteAddresses: List[String], localActorSystem) -- ClientConnection.scala:10
+class ClientConnection {
+ public:
+  // "host:port" strings are parsed exactly like the reference (split(":"), two fields) and turned into
+  // akka.tcp://ClusterSystem@host:port/user/regionRouter paths; `resolve` maps such a path to a Region.
+  ClientConnection(const std::vector<std::string> &remoteAddresses,
+                   std::function<std::shared_ptr<Region>(const std::string &routerPath)> resolve);
+  // def insertNewVector(vectors: Set[(String, SparkSparseVector)]): Unit -- fire and forget (ClientConnection.scala:31-33)
+  void insertNewVector(const std::vector<std::pair<std::string, SparkSparseVector>> &vectors);
+  const std::vector<std::string> &remoteAddressRouterList() const { return routers_; }
+ private:
+  std::vector<std::string> routers_;
+  std::shared_ptr<Region> remote_router_;
+};
+
+}  // namespace cpslab

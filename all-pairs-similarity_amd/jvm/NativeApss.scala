@@ -1,0 +1,15 @@
+package cpslab.gpu
+
+/** JNI face of libapss_hip.so (include/apss.h); see all-pairs-similarity_amd/jvm/apss_jni.c.
+  * Not compiled in the build image (no JVM there); it is the binding a maintainer adds to `core/`. */
+object NativeApss {
+  System.loadLibrary("apss_jni")
+  val FLAG_VALUE_PRUNE = 1
+  @native def create(dim: Int, theta: Double, indexThreshold: Double, flags: Int, device: Int): Long
+  @native def destroy(h: Long): Unit
+  @native def lastError(h: Long): String
+  /** mode 0 insert, 1 query on the frozen index, 2 insert-and-query; returns #results or a negative status */
+  @native def submit(h: Long, mode: Int, rowptr: Array[Long], indices: Array[Int], values: Array[Double],
+                     ids: Array[Long]): Long
+  @native def fetch(h: Long, count: Long, outQ: Array[Long], outC: Array[Long], outScore: Array[Float]): Int
+}

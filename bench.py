@@ -49,7 +49,8 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
     """The oracle's restatement of the reference algorithm ("port": posting lists + the per-candidate hash-map dot
     of CommonUtils.scala:98-117 in double), timed on this box's host cores on a bounded query sample."""
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16)  # one GPU's share of the host (the box exposes every core of the machine)
     n = len(rp) - 1
     pilot_q = min(n, cores * 2)
     p = oracle.selfjoin_sample(0, cfg["dim"], cfg["theta"], rp, idx, val, 0, pilot_q, cores)
@@ -231,6 +232,16 @@ def main():
             "note": "achieved = 8 B x posting visits per launch / HIP-event kernel time on the launch stream",
         },
     }
+    # HBM-side bytes per probe launch: rocprofv3 PMC passes cannot run inside this process; the committed summary of
+    # the same command (profiles/collect_r01.sh -> profiles/r01_probe_traffic.json) is quoted when the workload matches
+    tpath = os.path.join(ROOT, "profiles", "r01_probe_traffic.json")
+    if world == 1 and a.workload == "c3" and not a.n and not a.tile_rows and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("algorithmic_bytes_per_launch") == alg_bytes:
+            out["roofline"]["traffic"] = tj["traffic_bytes_per_launch_corrected"]
+            out["roofline"]["traffic_note"] = ("bytes per launch, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 "
+                                               "--pmc passes of this command (profiles/r01_probe_traffic.json); gfx950 tallies "
+                                               "128-B read requests at 64 B; Infinity-Cache hits are included")
     out.update(extra)
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds)

@@ -1,0 +1,55 @@
+"""Turns the raw rocprofv3 output that profiles/collect_r01.sh left under gpurun_out/r01 into the committed summaries
+profiles/r01_*.  Run from the repo root after a gpurun call."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+SRC = "gpurun_out/r01"
+DST = "profiles"
+
+
+def latest(pattern):
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1] if fs else None
+
+
+def pmc(dirname):
+    f = latest(os.path.join(SRC, dirname, "*", "*counter_collection.csv"))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        n[r["Kernel_Name"]].add(r["Dispatch_Id"])
+    return {k: {c: v / len(n[k]) for c, v in d.items()} for k, d in agg.items()}  # per launch
+
+
+stats = latest(os.path.join(SRC, "trace", "*", "*kernel_stats.csv"))
+shutil.copy(stats, os.path.join(DST, "r01_kernel_stats.csv"))
+bench = json.loads(open(os.path.join(SRC, "bench_default.json")).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(DST, "r01_bench_default.json"), "w"), indent=1)
+
+probe = lambda d: next(v for k, v in d.items() if "k_probe" in k)
+fetch, write, rd, l2 = probe(pmc("pmc_fetch")), probe(pmc("pmc_write")), probe(pmc("pmc_rdreq")), probe(pmc("pmc_l2"))
+rows = list(csv.DictReader(open(stats)))
+pk = next(r for r in rows if "k_probe" in r["Name"])
+alg = 8 * bench["posting_visits_per_step"]
+# MI355X_MICROARCH.md "HBM": FETCH_SIZE is in KB and tallies every 128-B read request at 64 B on gfx950 -> x2;
+# WRITE_SIZE is exact.  Confirmed for this access shape by profiles/microbench/fetch_calib.hip (all requests 128 B).
+traffic = fetch["FETCH_SIZE"] * 1024 * 2 + write["WRITE_SIZE"] * 1024
+out = {
+    "kernel": pk["Name"], "calls": int(pk["Calls"]), "avg_ms_rocprof": float(pk["AverageNs"]) / 1e6,
+    "avg_ms_bench_hip_events": bench["probe_kernel_ms"],
+    "algorithmic_bytes_per_launch": alg,
+    "FETCH_SIZE_KB_raw": fetch["FETCH_SIZE"], "WRITE_SIZE_KB_raw": write["WRITE_SIZE"],
+    "TCC_EA0_RDREQ": rd["TCC_EA0_RDREQ_sum"], "TCC_EA0_RDREQ_128B": rd["TCC_EA0_RDREQ_128B_sum"],
+    "traffic_bytes_per_launch_corrected": traffic,
+    "traffic_over_algorithmic": traffic / alg,
+    "memory_side_GBps": traffic / (float(pk["AverageNs"]) * 1e-9) / 1e9,
+    "l2_hit_rate": l2["TCC_HIT_sum"] / (l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"]),
+    "note": "traffic = L2 <-> fabric bytes (Infinity-Cache hits are counted, see the guide): an upper bound of HBM bytes",
+}
+json.dump(out, open(os.path.join(DST, "r01_probe_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
