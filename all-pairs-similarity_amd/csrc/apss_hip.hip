@@ -308,9 +308,9 @@ int32_t build_tiles(apss_handle *h, int64_t row0) {
   return APSS_OK;
 }
 
-template <int MODE>
+template <int MODE, bool FX>
 int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
-  auto kern = k_probe<MODE, kProbeBlock>;
+  auto kern = k_probe<MODE, kProbeBlock, FX>;
   HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(kProbeBlock), lds, h->stream, a);
   HIPCHK(h, hipGetLastError());
@@ -382,9 +382,14 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const int wave_survcap = (variant == 'A' || variant == 'B') ? 1024 : 512;
   // chunk descriptors pack (first posting * 8 + count - 1) into 32 bits: a tile's postings must number < 2^28
   const bool wave_path = mode == 0 && fx_scale > 0 && q_max_nnz <= wave_block && !(h->cfg.flags & APSS_FLAG_FORCE_GENERAL) &&
+                         !getenv("APSS_FORCE_GENERAL") &&
                          h->store_max_nnz * (int64_t)h->cb + (int64_t)kSegAlign * h->cfg.dim < (1LL << 28);
-  a.fx_scale = (float)fx_scale;
-  a.theta_fx = (uint32_t)std::min(4294967295.0, std::ceil(theta * fx_scale));
+  // the general kernel sums signed values: one bit less (2^29 / 2^27); unbounded norms keep fp32 atomics
+  const bool gen_fx = !wave_path && fx_scale > 0;
+  const double scale_used = wave_path ? fx_scale : fx_scale / 2;
+  a.fx_scale = (float)scale_used;
+  a.theta_fx = (uint32_t)std::min(4294967295.0, std::max(1.0, std::ceil(theta * scale_used)));
+  a.theta_fxi = (int32_t)std::max(-2147483647.0, std::min(2147483647.0, std::ceil(theta * scale_used)));
   const size_t lds = wave_path ? probe_wave_lds_bytes(h->cb, wave_block, wave_u, wave_longcap, wave_survcap)
                                : probe_lds_bytes(h->cb, kProbeBlock, mode);
   auto launch_wave = [&](bool diag) -> int32_t {
@@ -441,9 +446,15 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
               100.0 * d[5] / tot, 100.0 * d[6] / tot, (double)tot / ((double)a.n_tiles * a.nq * (wave_block / kWave)));
     } else if (wave_path) {
       APSS_TRY(launch_wave(false));
-    } else if (mode == 0) APSS_TRY(launch_probe<0>(h, a, lds));
-    else if (mode == 1) APSS_TRY(launch_probe<1>(h, a, lds));
-    else APSS_TRY(launch_probe<2>(h, a, lds));
+    } else if (gen_fx) {
+      if (mode == 0) APSS_TRY((launch_probe<0, true>(h, a, lds)));
+      else if (mode == 1) APSS_TRY((launch_probe<1, true>(h, a, lds)));
+      else APSS_TRY((launch_probe<2, true>(h, a, lds)));
+    } else {
+      if (mode == 0) APSS_TRY((launch_probe<0, false>(h, a, lds)));
+      else if (mode == 1) APSS_TRY((launch_probe<1, false>(h, a, lds)));
+      else APSS_TRY((launch_probe<2, false>(h, a, lds)));
+    }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     unsigned long long c[kCtrCount];
     HIPCHK(h, hipMemcpyAsync(c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));

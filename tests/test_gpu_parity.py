@@ -238,3 +238,26 @@ def test_c3_shape_properties(apss_mod):
     assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
     got2, _ = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=16384)
     assert_same_pairs(got2, got, theta, tol=2e-6)
+
+
+def test_unbounded_norms_use_the_float_path(apss_mod, oracle):
+    """row norms too large for the fixed-point accumulators (|q||c| >= 15.6): the fp32-atomic kernels must take over"""
+    n, dim, nnz = 1500, 300, 12
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=41, dup_frac=0.1)
+    big = val * 10.0  # norms 10 -> scores up to 100
+    theta = 45.0
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, big))
+    assert len(want) > 100
+    got, _ = _gpu_join(apss_mod, dim, theta, rp, idx, big, tile_rows=512)
+    assert_same_pairs(got, want, theta, band=1e-3, tol=1e-3)  # fp32 sums of values around 100
+
+
+def test_medium_norms_use_the_coarser_fixed_point_scale(apss_mod, oracle):
+    n, dim, nnz = 1500, 300, 12
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=42, dup_frac=0.1)
+    v3 = val * 3.0  # |q||c| = 9: scale 2^28
+    theta = 4.5
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, v3))
+    assert len(want) > 100
+    got, _ = _gpu_join(apss_mod, dim, theta, rp, idx, v3, tile_rows=512)
+    assert_same_pairs(got, want, theta, band=1e-4, tol=1e-4)  # inputs are fp32 on the device: 6e-8 * 9 * terms
