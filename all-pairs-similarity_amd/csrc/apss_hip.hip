@@ -176,7 +176,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   a.flags_out = h->flagword.p;
   const int threads = 256;
   const int64_t blocks = ceil_div(n * kGroup, threads);
-  hipLaunchKernelGGL(k_ingest_count, dim3((unsigned)blocks), dim3(threads), 0, h->stream, a);
+  hipLaunchKernelGGL(k_ingest_count<kGroup>, dim3((unsigned)blocks), dim3(threads), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
 
   // destination
@@ -237,11 +237,8 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
     w.row_dst = h->s_rowdst.p;
     w.nnz_dst = h->s_nnzdst.p;
   } else {
-    // identity placement: row r -> r, entry k -> k; reuse the batch rowptr as the entry scan and a ramp for rows
-    APSS_TRY(ensure(h, h->s_rowdst, (size_t)n + 1));
-    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->s_keep.p, h->s_rowdst.p, n);
-    HIPCHK(h, hipGetLastError());
-    w.row_dst = h->s_rowdst.p;
+    // identity placement: row r -> r, entry k -> k (the batch rowptr is the entry scan)
+    w.row_dst = nullptr;
     w.nnz_dst = d_rowptr;
   }
   hipLaunchKernelGGL(k_ingest_write, dim3((unsigned)blocks), dim3(threads), 0, h->stream, w);

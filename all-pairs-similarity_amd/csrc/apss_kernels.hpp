@@ -69,31 +69,35 @@ struct IngestArgs {
   unsigned int *flags_out;  // [0]: bit0 malformed indices, bit1 non-finite value, bit2 negative value kept; [1]: max kept row length; [2]: bits of the max squared row norm; [3]: non-empty kept rows
 };
 
-// one 16-lane group per row
+// one G-lane group per row (G = 16 for short rows, 64 for rows of about a hundred entries)
+template <int G>
 __global__ void k_ingest_count(IngestArgs a) {
-  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
-  const int gl = threadIdx.x % kGroup;
-  if (row >= a.n) return;
-  int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int gl = threadIdx.x % G;
+  int64_t b = 0, e = 0;
+  if (row < a.n) {
+    b = a.rowptr[row];
+    e = a.rowptr[row + 1];
+  }
   unsigned bad = 0;
   if (b < 0 || e < b || e > a.nnz) {  // malformed extents: flag the batch and read nothing
     bad |= 1;
     b = e = 0;
   }
   float sumsq = 0.f;
-  for (int64_t k = b + gl; k < e; k += kGroup) {
+  for (int64_t k = b + gl; k < e; k += G) {
     const float v = a.val[k];
     const int32_t t = a.idx[k];
     if (!(t >= 0 && t < a.dim) || (k > b && a.idx[k - 1] >= t)) bad |= 1;  // SV:75 strictly increasing, < size
     if (!isfinite(v)) bad |= 2;
     sumsq += v * v;
   }
-  for (int o = kGroup / 2; o; o >>= 1) sumsq += __shfl_xor(sumsq, o, kGroup);
+  for (int o = G / 2; o; o >>= 1) sumsq += __shfl_xor(sumsq, o, G);
   // LG:35-37: values / sqrt(foldLeft(sum + v*v))
   const float inv = (a.flags & 4u) ? (sumsq > 0.f ? 1.0f / sqrtf(sumsq) : 0.f) : 1.0f;
   float sum = 0.f, sub = 0.f;
   int cnt = 0;
-  for (int64_t k = b + gl; k < e; k += kGroup) {
+  for (int64_t k = b + gl; k < e; k += G) {
     const float v = a.val[k] * inv;
     const int32_t t = a.idx[k];
     sum += v;  // EPA:89 with max-weight 1.0
@@ -104,30 +108,42 @@ __global__ void k_ingest_count(IngestArgs a) {
       if (v < 0.f) bad |= 4;
     }
   }
-  for (int o = kGroup / 2; o; o >>= 1) {
-    sum += __shfl_xor(sum, o, kGroup);
-    sub += __shfl_xor(sub, o, kGroup);
-    cnt += __shfl_xor(cnt, o, kGroup);
-    bad |= __shfl_xor(bad, o, kGroup);
+  for (int o = G / 2; o; o >>= 1) {
+    sum += __shfl_xor(sum, o, G);
+    sub += __shfl_xor(sub, o, G);
+    cnt += __shfl_xor(cnt, o, G);
+    bad |= __shfl_xor(bad, o, G);
   }
-  if (gl == 0) {
+  // per-batch summaries: combine inside the workgroup (LDS atomics), then ONE global atomic each per workgroup --
+  // a million same-address global atomics were 4x the cost of everything else in this kernel
+  __shared__ unsigned sh[4];
+  if (threadIdx.x < 4) sh[threadIdx.x] = 0;
+  __syncthreads();
+  if (gl == 0 && row < a.n) {
     const bool admit = !(a.flags & 2u) || sum >= a.theta;  // EPA:89
     a.row_keep[row] = admit ? 1 : 0;
     a.row_cnt[row] = admit ? cnt : 0;
     a.row_inv[row] = inv;
     a.row_sub[row] = sqrtf(sub);
-    if (bad) atomicOr(a.flags_out, bad);
+    if (bad) atomicOr(&sh[0], bad);
     if (admit) {
-      atomicMax(a.flags_out + 1, (unsigned)cnt);         // longest kept row: picks the probe kernel
-      atomicMax(a.flags_out + 2, __float_as_uint(sub));  // largest squared L2 norm of a kept row (fixed-point range)
-      if (cnt > 0) atomicAdd(a.flags_out + 3, 1u);       // rows with at least one kept entry
+      atomicMax(&sh[1], (unsigned)cnt);         // longest kept row: picks the probe kernel
+      atomicMax(&sh[2], __float_as_uint(sub));  // largest squared L2 norm of a kept row (fixed-point range)
+      if (cnt > 0) atomicAdd(&sh[3], 1u);       // rows with at least one kept entry
     }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (sh[0]) atomicOr(a.flags_out, sh[0]);
+    if (sh[1]) atomicMax(a.flags_out + 1, sh[1]);
+    if (sh[2]) atomicMax(a.flags_out + 2, sh[2]);
+    if (sh[3]) atomicAdd(a.flags_out + 3, sh[3]);
   }
 }
 
 struct IngestWriteArgs {
   IngestArgs in;
-  const int64_t *row_dst;  // [n+1] exclusive scan of row_keep
+  const int64_t *row_dst;  // [n+1] exclusive scan of row_keep; null = no row is dropped
   const int64_t *nnz_dst;  // [n+1] exclusive scan of row_cnt
   int64_t dst_row0, dst_nnz0;  // where the batch lands in the destination arrays
   int64_t *o_rowptr;  // destination rowptr (absolute offsets); o_rowptr[dst_row0 + r + 1] is written
@@ -146,7 +162,7 @@ __global__ void k_ingest_write(IngestWriteArgs w) {
   if (!a.row_keep[row]) return;
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
   const float inv = a.row_inv[row];
-  const int64_t dr = w.dst_row0 + w.row_dst[row];
+  const int64_t dr = w.dst_row0 + (w.row_dst ? w.row_dst[row] : row);  // no row dropped: identity placement
   int64_t out = w.dst_nnz0 + w.nnz_dst[row];
   for (int64_t k0 = b; k0 < e; k0 += kGroup) {
     const int64_t k = k0 + gl;
