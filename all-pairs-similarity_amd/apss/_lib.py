@@ -8,7 +8,7 @@ CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 SO_PATH = os.path.join(CSRC, "libapss_hip.so")
 
 OK, E_INVALID, E_NOMEM, E_DEVICE, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-FLAG_VALUE_PRUNE, FLAG_ADMISSION, FLAG_NORMALIZE, FLAG_FORCE_SCAN, FLAG_FORCE_GENERAL = 1, 2, 4, 8, 16
+FLAG_VALUE_PRUNE, FLAG_ADMISSION, FLAG_NORMALIZE, FLAG_FORCE_SCAN, FLAG_FORCE_GENERAL, FLAG_EXACT_ACCUM = 1, 2, 4, 8, 16, 32
 
 # every symbol include/apss.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -29,7 +29,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("tiles", C.c_int64), ("posting_visits", C.c_int64),
                 ("candidate_pairs", C.c_int64), ("result_pairs", C.c_int64), ("probe_ms", C.c_double),
-                ("build_ms", C.c_double), ("probe_launches", C.c_int64), ("hbm_bytes", C.c_int64)]
+                ("build_ms", C.c_double), ("probe_launches", C.c_int64), ("hbm_bytes", C.c_int64),
+                ("filter_survivors", C.c_int64), ("rescore_ms", C.c_double)]
 
 
 def build(force=False):

@@ -51,14 +51,26 @@ struct apss_handle {
   DevBuf<int64_t> rowptr, ext;
   DevBuf<int32_t> idx;
   DevBuf<float> val, sub;  // sub: shard sub-norm per row (sharded only)
-  // index (tile-major CSC) -- invertedIndex, IWA:25
-  int64_t n_tiles = 0;
-  int64_t post_used = 0;  // posting records incl. segment alignment padding
-  DevBuf<uint2> tile_seg;
-  DevBuf<Posting> post;
+  // index (tile-major CSC) -- invertedIndex, IWA:25.  Two renderings of the same posting lists:
+  //   ex: exact, 8-B postings, `cb` rows per tile      (k_probe_wave, k_probe, shard mode)
+  //   cx: coarse, 4-B postings, up to 2*cb rows per tile (k_probe_coarse, the filter of the two-pass join)
+  struct IndexSet {
+    int32_t cb = 0;
+    int32_t align = 0;
+    bool coarse = false;
+    int64_t n_tiles = 0, post_used = 0;
+    DevBuf<uint2> seg;
+    DevBuf<Posting> post;
+    DevBuf<uint32_t> post_c;
+    DevBuf<int64_t> base, total;
+    std::vector<int64_t> h_base;
+    double build_ms = 0;
+  };
+  IndexSet ex, cx;
+  bool use_coarse = false;  // build and use the coarse index (non-sharded handles without APSS_FLAG_EXACT_ACCUM)
+  int64_t n_tiles = 0;      // tiles of the exact rendering (apss_stats)
+  int64_t ex_built_rows = 0;     // the exact rendering covers rows [0, ex_built_rows)
   DevBuf<float> tile_min;
-  DevBuf<int64_t> tile_base, tile_total;  // device: first posting of each tile (+ end), padded posting counts
-  std::vector<int64_t> h_tile_base;       // host mirror of tile_base
   // query staging (apss_query: batch not stored)
   DevBuf<int64_t> q_rowptr, q_ext;
   DevBuf<int32_t> q_idx;
@@ -68,8 +80,10 @@ struct apss_handle {
   DevBuf<int32_t> in_idx;
   DevBuf<float> s_inv, s_sub, in_val;
   // results of the last query-type call
-  DevBuf<int32_t> res_q, res_c;
-  DevBuf<float> res_s;
+  DevBuf<int32_t> res_q, res_c, fin_q, fin_c;
+  DevBuf<float> res_s, fin_s;
+  const int32_t *out_q = nullptr, *out_c = nullptr;  // where the last call's results live (res_* or fin_*)
+  const float *out_s = nullptr;
   int64_t n_res = -1;
   const int64_t *res_q_ext = nullptr;      // ext ids of the last query batch (device)
   const int64_t *last_q_rowptr = nullptr;  // last query batch CSR (device), for apss_partial_scores_dev
@@ -248,22 +262,22 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   return APSS_OK;
 }
 
-// ---- index build for rows [row0, n_rows): rebuild every tile that contains one of them ----
-int32_t build_tiles(apss_handle *h, int64_t row0) {
-  const int64_t cb = h->cb;
+// ---- index build for rows [row0, n_rows): rebuild every tile of `ix` that contains one of them ----
+int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
+  const int64_t cb = ix.cb;
   const int64_t tile0 = row0 / cb;
   const int64_t n_tiles = ceil_div(h->n_rows, cb);
   const int64_t stride = (int64_t)h->cfg.dim;
-  h->n_tiles = n_tiles;
+  ix.n_tiles = n_tiles;
   if (n_tiles == tile0) return APSS_OK;
-  APSS_TRY(ensure(h, h->tile_seg, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
-  APSS_TRY(ensure(h, h->tile_base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
-  APSS_TRY(ensure(h, h->tile_total, (size_t)n_tiles, 0));
-  if (h->sharded) APSS_TRY(ensure(h, h->tile_min, (size_t)n_tiles, (size_t)tile0));
-  if (h->h_tile_base.empty()) h->h_tile_base.push_back(0);
-  h->h_tile_base.resize((size_t)tile0 + 1);  // bases of the tiles that stay
+  APSS_TRY(ensure(h, ix.seg, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
+  APSS_TRY(ensure(h, ix.base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
+  APSS_TRY(ensure(h, ix.total, (size_t)n_tiles, 0));
+  if (h->sharded && !ix.coarse) APSS_TRY(ensure(h, h->tile_min, (size_t)n_tiles, (size_t)tile0));
+  if (ix.h_base.empty()) ix.h_base.push_back(0);
+  ix.h_base.resize((size_t)tile0 + 1);  // bases of the tiles that stay
   const int64_t r0 = tile0 * cb;
-  HIPCHK(h, hipMemsetAsync(h->tile_seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
+  HIPCHK(h, hipMemsetAsync(ix.seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
   BuildArgs b{};
   b.rowptr = h->rowptr.p;
   b.idx = h->idx.p;
@@ -272,28 +286,32 @@ int32_t build_tiles(apss_handle *h, int64_t row0) {
   b.row1 = h->n_rows;
   b.cb = (int32_t)cb;
   b.dim = h->cfg.dim;
-  b.tile_seg = h->tile_seg.p;
+  b.tile_seg = ix.seg.p;
   b.seg_stride = stride;
+  b.coarse = ix.coarse ? 1 : 0;
+  b.seg_align = ix.align;
   const int threads = 256;
   const int64_t blocks = ceil_div((h->n_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
-  hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, h->tile_seg.p, stride,
-                     h->cfg.dim, tile0, h->tile_total.p);
+  hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, ix.seg.p, stride, h->cfg.dim,
+                     tile0, ix.total.p, (uint32_t)ix.align);
   HIPCHK(h, hipGetLastError());
   // padded posting counts -> tile bases (host prefix sum: a handful of values), then reserve the posting array
   std::vector<int64_t> tot((size_t)(n_tiles - tile0));
-  HIPCHK(h, hipMemcpyAsync(tot.data(), h->tile_total.p + tile0, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(tot.data(), ix.total.p + tile0, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (size_t i = 0; i < tot.size(); ++i) h->h_tile_base.push_back(h->h_tile_base.back() + tot[i]);
-  HIPCHK(h, hipMemcpyAsync(h->tile_base.p + tile0, h->h_tile_base.data() + tile0, (size_t)(n_tiles - tile0 + 1) * sizeof(int64_t),
+  for (size_t i = 0; i < tot.size(); ++i) ix.h_base.push_back(ix.h_base.back() + tot[i]);
+  HIPCHK(h, hipMemcpyAsync(ix.base.p + tile0, ix.h_base.data() + tile0, (size_t)(n_tiles - tile0 + 1) * sizeof(int64_t),
                            hipMemcpyHostToDevice, h->stream));
-  h->post_used = h->h_tile_base.back();
-  APSS_TRY(ensure(h, h->post, (size_t)h->post_used + 64, (size_t)h->h_tile_base[(size_t)tile0]));
-  b.tile_post_base = h->tile_base.p;
-  b.post = h->post.p;
+  ix.post_used = ix.h_base.back();
+  if (ix.coarse) APSS_TRY(ensure(h, ix.post_c, (size_t)ix.post_used + 64, (size_t)ix.h_base[(size_t)tile0]));
+  else APSS_TRY(ensure(h, ix.post, (size_t)ix.post_used + 64, (size_t)ix.h_base[(size_t)tile0]));
+  b.tile_post_base = ix.base.p;
+  b.post = ix.post.p;
+  b.post_c = ix.post_c.p;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
-  if (h->sharded)
+  if (h->sharded && !ix.coarse)
     hipLaunchKernelGGL(k_tile_min_sub, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream,
                        (const float *)h->sub.p, h->n_rows, (int32_t)cb, h->tile_min.p, tile0);
   HIPCHK(h, hipGetLastError());
@@ -301,7 +319,32 @@ int32_t build_tiles(apss_handle *h, int64_t row0) {
   HIPCHK(h, hipEventSynchronize(h->ev1));
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  h->st.build_ms = ms;
+  ix.build_ms = ms;
+  return APSS_OK;
+}
+
+// Which renderings of the index a handle keeps: the coarse one (two-pass speed path) is built at insert time when the
+// handle may use it; the exact one is built at insert time otherwise, or lazily by the first probe that needs it.
+int32_t ensure_exact_index(apss_handle *h) {
+  if (h->ex_built_rows < h->n_rows || h->ex.n_tiles == 0) {
+    APSS_TRY(build_tiles(h, h->ex, std::min(h->ex_built_rows, h->n_rows)));
+    h->ex_built_rows = h->n_rows;
+    h->st.build_ms += h->ex.build_ms;
+  }
+  return APSS_OK;
+}
+
+int32_t build_index(apss_handle *h, int64_t row0) {
+  h->st.build_ms = 0;
+  if (h->use_coarse) {
+    APSS_TRY(build_tiles(h, h->cx, row0));
+    h->st.build_ms += h->cx.build_ms;
+    h->ex_built_rows = std::min(h->ex_built_rows, row0 / h->ex.cb * h->ex.cb);  // exact tiles from here on are stale
+  } else {
+    h->ex_built_rows = std::min(h->ex_built_rows, row0);
+    APSS_TRY(ensure_exact_index(h));
+  }
+  h->n_tiles = ceil_div(h->n_rows, h->ex.cb);
   return APSS_OK;
 }
 
@@ -329,7 +372,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.probe_launches = 0;
   if (n_results) *n_results = 0;
   APSS_TRY(ensure(h, h->counters, kCtrCount));
-  if (nq == 0 || h->n_tiles == 0 || q_nnz_end <= 0 || h->nnz == 0) return APSS_OK;  // nothing can share a term
+  h->st.filter_survivors = 0;
+  h->st.rescore_ms = 0;
+  if (nq == 0 || h->n_rows == 0 || q_nnz_end <= 0 || h->nnz == 0) return APSS_OK;  // nothing can share a term
   if (nq > 0x7fffffffLL) return fail(h, APSS_E_INVALID, "query batch too large");
 
   const double theta = h->cfg.theta;
@@ -338,17 +383,24 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   else if (!h->nonneg || (h->cfg.flags & APSS_FLAG_FORCE_SCAN)) mode = 1;
   else mode = 0;
 
+  // every partial score must fit the fixed-point accumulators: by Cauchy-Schwarz a partial sum of non-negative
+  // products is at most |q| * |c| <= the product of the largest row norms
+  const double bound = std::sqrt((double)q_max_norm2) * std::sqrt((double)h->store_max_norm2) * 1.0001 + 1e-6;
+  const double fx_scale = bound < 3.9 ? 1073741824.0 : (bound < 15.6 ? 268435456.0 : 0.0);
+  const bool forced_general = (h->cfg.flags & APSS_FLAG_FORCE_GENERAL) || getenv("APSS_FORCE_GENERAL");
+
+  // ---- path 1: two-pass join (coarse filter + exact rescoring) ----
+  const double cx_scale = bound < 1.9 ? 32768.0 : 16384.0;
+  const double cx_theta = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
+  const bool coarse_path = h->use_coarse && mode == 0 && bound < 3.9 && q_max_nnz <= 512 && !forced_general &&
+                           !getenv("APSS_EXACT_ACCUM") && cx_theta - (double)(q_max_nnz + 1) / 2 - 2 >= 1.0 &&
+                           h->store_max_nnz * (int64_t)h->cx.cb + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
+
   ProbeArgs a{};
-  a.tile_seg = h->tile_seg.p;
   a.seg_stride = (int64_t)h->cfg.dim;
-  a.post = h->post.p;
-  a.tile_post_base = h->tile_base.p;
   a.ext_id = h->ext.p;
   a.c_scale = h->sharded ? h->sub.p : nullptr;
-  a.tile_scale = h->sharded ? h->tile_min.p : nullptr;
   a.n_rows = h->n_rows;
-  a.cb = h->cb;
-  a.n_tiles = (int32_t)h->n_tiles;
   a.q_rowptr = q_rowptr;
   a.q_idx = q_idx;
   a.q_val = q_val;
@@ -364,31 +416,42 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.q_slot_base = q_slot_base;
   a.theta = (float)theta;
   a.counters = h->counters.p;
-  // speed path (k_probe_wave): fixed-point accumulators need every partial score to fit: by Cauchy-Schwarz a
-  // partial sum of non-negative products is at most |q| * |c| <= the product of the largest row norms.
-  const double bound = std::sqrt((double)q_max_norm2) * std::sqrt((double)h->store_max_norm2) * 1.0001 + 1e-6;
-  const double fx_scale = bound < 3.9 ? 1073741824.0 : (bound < 15.6 ? 268435456.0 : 0.0);
-  // kernel shapes: A = 8 waves x 64-chunk window, one workgroup per CU at 32768-row tiles; C = 8 waves x 40-chunk
-  // window, sized so that TWO workgroups share a CU at 16384-row tiles (their barriers and LDS bursts interleave)
-  const char *var_env = getenv("APSS_WAVE_VARIANT");  // test / A-B hook: A, B, C or D
-  char variant = var_env ? var_env[0] : (h->cb <= 16384 ? 'C' : 'A');
-  if (variant != 'A' && variant != 'B' && variant != 'C' && variant != 'D') variant = 'A';
+  a.cx_scale = (float)cx_scale;
+  a.cx_theta = (float)cx_theta;
+
+  apss_handle::IndexSet &ix = coarse_path ? h->cx : h->ex;
+  if (!coarse_path) APSS_TRY(ensure_exact_index(h));
+  a.tile_seg = ix.seg.p;
+  a.post = h->ex.post.p;
+  a.post_c = h->cx.post_c.p;
+  a.tile_post_base = ix.base.p;
+  a.tile_scale = h->sharded ? h->tile_min.p : nullptr;
+  a.cb = ix.cb;
+  a.n_tiles = (int32_t)ix.n_tiles;
+
+  // ---- path 2: single-pass exact speed kernel (k_probe_wave); kernel shapes: A = 8 waves x 64-chunk window, one
+  // workgroup per CU at 32768-row tiles; C = 8 waves x 40-chunk window, TWO workgroups per CU at <= 16384-row tiles
+  const char *var_env = getenv("APSS_WAVE_VARIANT");  // test / A-B hook
+  char variant = var_env ? var_env[0] : (h->ex.cb <= 16384 ? 'C' : 'A');
+  if (variant != 'A' && variant != 'B' && variant != 'C' && variant != 'D' && variant != 'E') variant = 'A';
   const int wave_block = variant == 'B' ? 1024 : (variant == 'D' ? 256 : 512);
   const int wave_u = (variant == 'A' || variant == 'D') ? 8 : 5;
-  const int wave_longcap = (variant == 'A' || variant == 'B') ? 256 : 128;
-  const int wave_survcap = (variant == 'A' || variant == 'B') ? 1024 : 512;
+  const int wave_longcap = (variant == 'A' || variant == 'B') ? 256 : (variant == 'E' ? 64 : 128);
+  const int wave_survcap = (variant == 'A' || variant == 'B') ? 1024 : (variant == 'E' ? 256 : 512);
   // chunk descriptors pack (first posting * 8 + count - 1) into 32 bits: a tile's postings must number < 2^28
-  const bool wave_path = mode == 0 && fx_scale > 0 && q_max_nnz <= wave_block && !(h->cfg.flags & APSS_FLAG_FORCE_GENERAL) &&
-                         !getenv("APSS_FORCE_GENERAL") &&
-                         h->store_max_nnz * (int64_t)h->cb + (int64_t)kSegAlign * h->cfg.dim < (1LL << 28);
-  // the general kernel sums signed values: one bit less (2^29 / 2^27); unbounded norms keep fp32 atomics
-  const bool gen_fx = !wave_path && fx_scale > 0;
+  const bool wave_path = !coarse_path && mode == 0 && fx_scale > 0 && q_max_nnz <= wave_block && !forced_general &&
+                         h->store_max_nnz * (int64_t)h->ex.cb + (int64_t)kSegAlign * h->cfg.dim < (1LL << 28);
+  // ---- path 3: general kernel (k_probe): signed fixed point when the norms are bounded, else fp32 atomics ----
+  const bool gen_fx = !coarse_path && !wave_path && fx_scale > 0;
   const double scale_used = wave_path ? fx_scale : fx_scale / 2;
   a.fx_scale = (float)scale_used;
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::max(1.0, std::ceil(theta * scale_used)));
   a.theta_fxi = (int32_t)std::max(-2147483647.0, std::min(2147483647.0, std::ceil(theta * scale_used)));
-  const size_t lds = wave_path ? probe_wave_lds_bytes(h->cb, wave_block, wave_u, wave_longcap, wave_survcap)
-                               : probe_lds_bytes(h->cb, kProbeBlock, mode);
+  const bool coarse_two = h->cx.cb <= 16384;  // small coarse tiles (tests): same shape, smaller lists
+  const size_t lds = coarse_path ? probe_coarse_lds_bytes(h->cx.cb, 512, 5, 128, 512)
+                     : wave_path ? probe_wave_lds_bytes(h->ex.cb, wave_block, wave_u, wave_longcap, wave_survcap)
+                                 : probe_lds_bytes(h->ex.cb, kProbeBlock, mode);
+  (void)coarse_two;
   auto launch_wave = [&](bool diag) -> int32_t {
     const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
 #define APSS_LAUNCH_WAVE1(B, UU, LC, SC, SH, DG)                                                                         \
@@ -405,6 +468,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     if (variant == 'A') APSS_LAUNCH_WAVE(512, 8, 256, 1024);
     else if (variant == 'B') APSS_LAUNCH_WAVE(1024, 5, 256, 1024);
     else if (variant == 'C') APSS_LAUNCH_WAVE(512, 5, 128, 512);
+    else if (variant == 'E') APSS_LAUNCH_WAVE(512, 5, 64, 256);
     else APSS_LAUNCH_WAVE(256, 8, 128, 512);
 #undef APSS_LAUNCH_WAVE1
 #undef APSS_LAUNCH_WAVE
@@ -426,7 +490,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     a.res_cap = h->res_q.cap;
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (wave_path && getenv("APSS_DIAG")) {
+    if (coarse_path) {
+      auto kern = k_probe_coarse<512, 5, 128, 512>;
+      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
+      HIPCHK(h, hipGetLastError());
+    } else if (wave_path && getenv("APSS_DIAG")) {
       // diagnostic build: in-kernel cycle stamps per round segment (shares only; never a benchmark number)
       APSS_TRY(ensure(h, h->dbg, 8));
       HIPCHK(h, hipMemsetAsync(h->dbg.p, 0, 8 * sizeof(unsigned long long), h->stream));
@@ -462,19 +531,65 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     h->st.probe_launches++;
     h->st.posting_visits = (int64_t)c[kCtrVisits];
     h->st.candidate_pairs = (int64_t)c[kCtrCands];
-    // the speed path counts a stored query's touch of its own slot; it is not a (q, c != q) pair
-    if (wave_path && q_slot_base >= 0) h->st.candidate_pairs -= (q_slot_base == 0 && nq == h->n_rows) ? h->store_nonempty : h->last_batch_nonempty;
+    // the speed paths count a stored query's touch of its own slot; it is not a (q, c != q) pair
+    if ((wave_path || coarse_path) && q_slot_base >= 0)
+      h->st.candidate_pairs -= (q_slot_base == 0 && nq == h->n_rows) ? h->store_nonempty : h->last_batch_nonempty;
     h->st.result_pairs = (int64_t)c[kCtrResults];
-    if (c[kCtrResults] <= a.res_cap) {
-      h->n_res = (int64_t)c[kCtrResults];
-      if (n_results) *n_results = h->n_res;
-      return APSS_OK;
+    if (c[kCtrResults] > a.res_cap) {
+      // the result list overflowed: grow to what the run asked for and repeat the (idempotent) probe
+      const size_t need = (size_t)c[kCtrResults] + (size_t)c[kCtrResults] / 8 + 1024;
+      APSS_TRY(ensure(h, h->res_q, need, 0, true));
+      APSS_TRY(ensure(h, h->res_c, need, 0, true));
+      APSS_TRY(ensure(h, h->res_s, need, 0, true));
+      continue;
     }
-    // the result list overflowed: grow to what the run asked for and repeat the (idempotent) probe
-    const size_t need = (size_t)c[kCtrResults] + (size_t)c[kCtrResults] / 8 + 1024;
-    APSS_TRY(ensure(h, h->res_q, need, 0, true));
-    APSS_TRY(ensure(h, h->res_c, need, 0, true));
-    APSS_TRY(ensure(h, h->res_s, need, 0, true));
+    h->n_res = (int64_t)c[kCtrResults];
+    h->out_q = h->res_q.p;
+    h->out_c = h->res_c.p;
+    h->out_s = h->res_s.p;
+    if (coarse_path) {
+      // exact pass: re-score what the filter let through from the fp32 store and prune at theta
+      const int64_t n_cand = h->n_res;
+      h->st.filter_survivors = n_cand;
+      h->n_res = 0;
+      if (n_cand > 0) {
+        APSS_TRY(ensure(h, h->fin_q, (size_t)n_cand, 0, true));
+        APSS_TRY(ensure(h, h->fin_c, (size_t)n_cand, 0, true));
+        APSS_TRY(ensure(h, h->fin_s, (size_t)n_cand, 0, true));
+        HIPCHK(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
+        RescoreArgs r{};
+        r.n_pairs = n_cand;
+        r.q_row = h->res_q.p;
+        r.c_slot = h->res_c.p;
+        r.q_rowptr = q_rowptr;
+        r.q_idx = q_idx;
+        r.q_val = q_val;
+        r.c_rowptr = h->rowptr.p;
+        r.c_idx = h->idx.p;
+        r.c_val = h->val.p;
+        r.theta = (float)theta;
+        r.out_q = h->fin_q.p;
+        r.out_c = h->fin_c.p;
+        r.out_s = h->fin_s.p;
+        r.out_count = h->counters.p;
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(n_cand * kGroup, 256)), dim3(256), 0, h->stream, r);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        unsigned long long nfin = 0;
+        HIPCHK(h, hipMemcpyAsync(&nfin, h->counters.p, sizeof(nfin), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->st.rescore_ms = ms;
+        h->n_res = (int64_t)nfin;
+      }
+      h->out_q = h->fin_q.p;
+      h->out_c = h->fin_c.p;
+      h->out_s = h->fin_s.p;
+      h->st.result_pairs = h->n_res;
+    }
+    if (n_results) *n_results = h->n_res;
+    return APSS_OK;
   }
   return fail(h, APSS_E_STATE, "result buffer kept overflowing");
 }
@@ -523,7 +638,7 @@ int32_t insert_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d
   const int64_t row0 = h->n_rows;
   h->n_rows += kept_rows;
   h->nnz += kept_nnz;
-  APSS_TRY(build_tiles(h, row0));
+  APSS_TRY(build_index(h, row0));
   return APSS_OK;
 }
 
@@ -564,7 +679,13 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
     return APSS_E_INVALID;
   }
   h->sharded = !(h->cfg.term_lo == 0 && h->cfg.term_hi == cfg->dim);
+  h->use_coarse = !h->sharded && !(cfg->flags & (APSS_FLAG_EXACT_ACCUM | APSS_FLAG_FORCE_GENERAL | APSS_FLAG_FORCE_SCAN));
   h->cb = cfg->tile_rows ? cfg->tile_rows : 16384;
+  h->ex.cb = h->cb;
+  h->ex.align = kSegAlign;
+  h->cx.cb = std::min(2 * h->cb, 32768);
+  h->cx.align = kSegAlignC;
+  h->cx.coarse = true;
   if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {
     g_create_error = "tile_rows must be a multiple of 64 in [64, 32768]";
     delete h;
@@ -602,7 +723,8 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   if (cfg->capacity_nnz > 0) {
     if (ensure(h, h->idx, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
         ensure(h, h->val, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
-        ensure(h, h->post, (size_t)cfg->capacity_nnz + (size_t)cfg->capacity_nnz / 2 + 64, 0, true) != APSS_OK) {
+        (h->use_coarse ? ensure(h, h->cx.post_c, (size_t)cfg->capacity_nnz * 2 + 64, 0, true)
+                       : ensure(h, h->ex.post, (size_t)cfg->capacity_nnz + (size_t)cfg->capacity_nnz / 2 + 64, 0, true)) != APSS_OK) {
       g_create_error = h->err;
       apss_destroy(h);
       return APSS_E_NOMEM;
@@ -617,7 +739,8 @@ void apss_destroy(apss_handle *h) {
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   release(h->rowptr); release(h->ext); release(h->idx); release(h->val); release(h->sub);
-  release(h->tile_seg); release(h->post); release(h->tile_min); release(h->tile_base); release(h->tile_total);
+  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); }
+  release(h->tile_min); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
   release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val);
@@ -697,12 +820,12 @@ int32_t apss_fetch_results(apss_handle *h, int64_t offset, int64_t count, int64_
   APSS_TRY(ensure(h, h->s_rowdst, (size_t)count));
   APSS_TRY(ensure(h, h->s_nnzdst, (size_t)count));
   hipLaunchKernelGGL(k_gather_ids, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, h->stream,
-                     (const int32_t *)h->res_q.p + offset, (const int32_t *)h->res_c.p + offset, h->res_q_ext,
+                     h->out_q + offset, h->out_c + offset, h->res_q_ext,
                      (const int64_t *)h->ext.p, count, h->s_rowdst.p, h->s_nnzdst.p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(out_q, h->s_rowdst.p, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(out_c, h->s_nnzdst.p, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(out_score, h->res_s.p + offset, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out_score, h->out_s + offset, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return APSS_OK;
 }
@@ -718,7 +841,7 @@ int32_t apss_stats_get(apss_handle *h, apss_stats *out) {
   if (!h || !out) return APSS_E_INVALID;
   h->st.rows = h->n_rows;
   h->st.nnz = h->nnz;
-  h->st.tiles = h->n_tiles;
+  h->st.tiles = h->use_coarse && h->ex_built_rows < h->n_rows ? h->cx.n_tiles : ceil_div(h->n_rows, h->ex.cb);
   h->st.hbm_bytes = (int64_t)h->bytes_reserved;
   *out = h->st;
   return APSS_OK;
@@ -764,8 +887,8 @@ int32_t apss_clear(apss_handle *h) {
   h->n_rows = 0;
   h->nnz = 0;
   h->n_tiles = 0;
-  h->post_used = 0;
-  h->h_tile_base.clear();
+  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { s->n_tiles = 0; s->post_used = 0; s->h_base.clear(); }
+  h->ex_built_rows = 0;
   h->n_res = -1;
   h->nonneg = true;
   h->store_max_nnz = 0;
@@ -778,9 +901,9 @@ int32_t apss_results_dev(apss_handle *h, const int32_t **d_q_row, const int32_t 
                          int64_t *n_results) {
   if (!h) return APSS_E_INVALID;
   if (h->n_res < 0) return fail(h, APSS_E_STATE, "no query has run on this handle");
-  if (d_q_row) *d_q_row = h->res_q.p;
-  if (d_c_slot) *d_c_slot = h->res_c.p;
-  if (d_score) *d_score = h->res_s.p;
+  if (d_q_row) *d_q_row = h->out_q;
+  if (d_c_slot) *d_c_slot = h->out_c;
+  if (d_score) *d_score = h->out_s;
   if (n_results) *n_results = h->n_res;
   return APSS_OK;
 }

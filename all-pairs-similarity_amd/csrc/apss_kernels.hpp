@@ -14,6 +14,7 @@
 // records {u32 local slot, f32 weight} of its rows grouped by term, every (tile, term) segment starting on a 128-B
 // boundary (16 postings), and a table tile_seg[T][dim] of {first posting, length} per term.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -225,7 +226,14 @@ __global__ __launch_bounds__(1024) void k_scan_i64(const int64_t *in, int64_t *o
 // segments, which cut the probe's memory-side traffic by a quarter (profiles/r01_summary.md).
 // k_tile_hist counts lengths into .y; k_tile_scan turns them into aligned starts (.x) and clears .y;
 // k_tile_scatter's cursor increments rebuild .y while placing the postings.
-constexpr int kSegAlign = 16;
+constexpr int kSegAlign = 16;   // exact index: 16 postings of 8 B = one 128-B line
+constexpr int kSegAlignC = 32;  // coarse index: 32 postings of 4 B = one 128-B line
+
+// coarse posting: u16 slot-in-tile | fp16 weight << 16 (4 B).  Read only by the coarse filter pass; every pair it
+// lets through is re-scored from the fp32 store.
+__device__ __forceinline__ uint32_t pack_coarse(uint32_t slot, float w) {
+  return (slot & 0xffffu) | ((uint32_t)__half_as_ushort(__float2half_rn(w)) << 16);
+}
 
 struct BuildArgs {
   const int64_t *rowptr;
@@ -237,7 +245,10 @@ struct BuildArgs {
   uint2 *tile_seg;
   int64_t seg_stride;             // dim
   const int64_t *tile_post_base;  // [n_tiles + 1] first posting of each tile in `post`
-  Posting *post;
+  Posting *post;                  // exact format (8 B) ...
+  uint32_t *post_c;               // ... or coarse format (4 B), when `coarse`
+  int32_t coarse;
+  int32_t seg_align;              // postings per aligned unit (kSegAlign / kSegAlignC)
 };
 
 // one wave per row: coalesced reads of the row's entries
@@ -252,14 +263,14 @@ __global__ void k_tile_hist(BuildArgs a) {
 
 // one workgroup per tile: exclusive scan of the aligned lengths; tile_total[tile] = postings incl. padding
 __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0,
-                                                    int64_t *tile_total) {
+                                                    int64_t *tile_total, uint32_t align) {
   __shared__ uint32_t part[1024];
   uint2 *sg = tile_seg + (tile0 + blockIdx.x) * seg_stride;
   const int tid = threadIdx.x;
   const int32_t per = (dim + 1023) / 1024;
   const int32_t b = tid * per, e = b + per < dim ? b + per : dim;
   uint32_t s = 0;
-  for (int32_t i = b; i < e; ++i) s += (sg[i].y + kSegAlign - 1) / kSegAlign * kSegAlign;
+  for (int32_t i = b; i < e; ++i) s += (sg[i].y + align - 1) / align * align;
   part[tid] = s;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
   for (int32_t i = b; i < e; ++i) {
     const uint32_t len = sg[i].y;
     sg[i] = make_uint2(run, 0u);
-    run += (len + kSegAlign - 1) / kSegAlign * kSegAlign;
+    run += (len + align - 1) / align * align;
   }
   if (tid == 1023) tile_total[tile0 + blockIdx.x] = part[1023];
 }
@@ -283,16 +294,20 @@ __global__ void k_tile_scatter(BuildArgs a) {
   if (row >= a.row1) return;
   const int64_t tile = row / a.cb;
   uint2 *sg = a.tile_seg + tile * a.seg_stride;
-  Posting *post = a.post + a.tile_post_base[tile];
+  const int64_t pbase = a.tile_post_base[tile];
   const uint32_t local = (uint32_t)(row - tile * a.cb);
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
   for (int64_t k = b + lane; k < e; k += kWave) {
     const int32_t t = a.idx[k];
     const uint32_t pos = sg[t].x + atomicAdd(&sg[t].y, 1u);
-    Posting p;
-    p.slot = local;
-    p.w = a.val[k];
-    post[pos] = p;
+    if (a.coarse) {
+      a.post_c[pbase + pos] = pack_coarse(local, a.val[k]);
+    } else {
+      Posting p;
+      p.slot = local;
+      p.w = a.val[k];
+      a.post[pbase + pos] = p;
+    }
   }
 }
 
@@ -345,6 +360,9 @@ struct ProbeArgs {
   float fx_scale;     // fixed-point accumulators: 1.0 is this many units (2^30 or 2^28), k_probe_wave
   uint32_t theta_fx;  // ceil(theta * fx_scale), computed in double on the host
   int32_t theta_fxi;  // the same, signed (theta <= 0 allowed): k_probe<.., FX>
+  const uint32_t *post_c;  // coarse postings (k_probe_coarse)
+  float cx_scale;          // coarse accumulator units per 1.0 (2^15 or 2^14)
+  float cx_theta;          // theta * cx_scale * (1 - 2^-11 - 1e-6): the coarse threshold before the per-query slack
   // output
   int32_t *res_q;
   int32_t *res_c;
@@ -1080,6 +1098,393 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
   if (tid == 0) {
     atomicAdd(&a.counters[kCtrVisits], stat[0]);
     atomicAdd(&a.counters[kCtrCands], stat[1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_probe_coarse: FILTER pass of the two-pass exact join.  Same structure as k_probe_wave, but it reads the coarse
+// index (4-B postings {u16 slot, fp16 weight}, 32 per 128-B line) and sums into 16-bit LDS accumulators (two
+// candidates per 32-bit word), so a tile holds 32768 candidates in 64 KB: half the (query, tile) rounds of the exact
+// kernel at two workgroups per CU, and about half the memory-side bytes per posting visit.
+// It reports every pair whose coarse sum reaches  floor(theta*S*(1 - 2^-11 - 1e-6)) - ceil(nnz_q/2) - 2  (S = cx_scale).
+// No true pair is lost: fp16 rounds a weight by at most 2^-11 relative, each product is rounded once to an
+// integer (<= 1/2 unit), integer sums are exact, so  coarse >= S*true*(1 - 2^-11) - nnz_q/2.  The survivors (a few
+// per thousand more than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.
+template <int BLOCK, int U, int LONGCAP, int SURVCAP>
+__global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
+  constexpr int NW = BLOCK / kWave;
+  constexpr int CH = 16;                 // postings per chunk: 8 lanes x 2 postings (8 B per lane)
+  constexpr int LPC = 8;                 // lanes per chunk
+  constexpr int GPW = kWave / LPC;       // chunks per wave step
+  constexpr int WIN = GPW * U;
+  static_assert(WIN <= kWave, "the window strip is cleared by one store per lane");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t *acc = (uint32_t *)smem_raw;                   // [cb / 2] words, two u16 accumulators each (+ slack)
+  uint2 *items = (uint2 *)(acc + a.cb / 2 + kWave);       // [NW][WIN] {first posting * 16 + (count - 1), weight bits}
+  uint2 *longs = (uint2 *)(items + NW * WIN);             // [3][LONGCAP]
+  float *long_w = (float *)(longs + 3 * LONGCAP);         // [3][LONGCAP]
+  uint32_t *surv = (uint32_t *)(long_w + 3 * LONGCAP);    // [SURVCAP]
+  uint32_t *ctr = surv + SURVCAP;
+  unsigned long long *stat = reinterpret_cast<unsigned long long *>(ctr + 8);
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
+  const int cb = a.cb;
+  const int tile = blockIdx.x / a.n_chunks;
+  const int chunk = blockIdx.x % a.n_chunks;
+  const int q0 = chunk * a.q_chunk;
+  const int q1 = min(a.nq, q0 + a.q_chunk);
+  const int64_t tile_row0 = (int64_t)tile * cb;
+  const int kterm = ln * NW + wv;
+  const uint32_t lo = (uint32_t)(ln % LPC);  // this lane handles postings 2*lo and 2*lo + 1 of its chunk
+  uint2 *wl = items + wv * WIN;
+  const float cxs = a.cx_scale;
+
+  const int64_t qbase = a.q_rowptr[q0], qend = a.q_rowptr[q1];
+  const int64_t pbase = a.tile_post_base[tile], pend = a.tile_post_base[tile + 1];
+  const __amdgpu_buffer_rsrc_t rs_qi =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_idx + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_qv =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_val + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_tp = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.tile_seg + (int64_t)tile * a.seg_stride), 0, (int)(a.seg_stride * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_po =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.post_c + pbase), 0, (int)((pend - pbase) * 4), 0x00020000);
+  constexpr uint32_t kOob = 0xfffffff0u;
+
+  for (int i = tid * 4; i < cb / 2 + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < 16) ctr[tid] = 0;
+  unsigned long long my_visits = 0;
+  uint32_t my_cands = 0;
+  uint32_t n_long_next = 0;
+
+  struct RowExt { int qb; int nnz; };
+  struct TermW { uint32_t term; float w; bool valid; };
+  struct Seg { uint32_t s, len; float w; };
+  struct WaveWork {
+    uint32_t s, len, excl;
+    float w;
+    int totch, tw;
+    apss_u32x2 pc[U];   // two coarse postings per lane and step
+    float wq0[U], wq1[U];  // query weight x cx_scale for each of them; 0 past the chunk's end
+  };
+  auto load_R = [&](int q) {
+    RowExt r;
+    const int qq = min(q, a.nq - 1);
+    const int64_t b = a.q_rowptr[qq], e = a.q_rowptr[qq + 1];
+    r.qb = (int)(b - qbase);
+    r.nnz = q < q1 ? (int)(e - b) : 0;
+    return r;
+  };
+  auto load_I = [&](const RowExt &r) {
+    TermW t;
+    t.valid = kterm < r.nnz;
+    const uint32_t off = t.valid ? (uint32_t)(r.qb + kterm) * 4u : kOob;
+    t.term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
+    t.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0));
+    return t;
+  };
+  auto load_P = [&](const TermW &t) {
+    Seg g;
+    const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, t.term * 8u, 0, 0);
+    g.s = sg.x;
+    g.len = t.valid ? sg.y : 0u;
+    g.w = t.w;
+    return g;
+  };
+  auto flatten = [&](WaveWork &f, const Seg &g, const RowExt &r, int li) {
+    uint32_t len = g.len;
+    my_visits += len;
+    if (len > (uint32_t)kLongLenW) {
+      const uint32_t k = atomicAdd(&ctr[li], 1u);
+      if (k < (uint32_t)LONGCAP) {
+        longs[li * LONGCAP + k] = make_uint2(g.s, len);
+        long_w[li * LONGCAP + k] = g.w;
+        len = 0;
+      }
+    }
+    const uint32_t nch = (len + CH - 1) / CH;
+    const uint32_t incl = wave_incl_scan(nch);
+    const uint32_t excl = incl - nch;
+    f.s = g.s;
+    f.len = len;
+    f.excl = excl;
+    f.w = g.w;
+    f.tw = wv < r.nnz ? (r.nnz - wv + NW - 1) / NW : 0;
+    f.totch = __builtin_amdgcn_readlane((int)incl, kWave - 1);
+    if (ln < WIN) wl[ln] = make_uint2(0u, 0u);
+    const uint32_t wbits = __float_as_uint(cxs * g.w);
+    auto put = [&](const uint32_t k) {
+      if (k < nch && excl + k < (uint32_t)WIN)
+        wl[excl + k] = make_uint2((g.s + k * CH) * 16u + (min((uint32_t)CH, len - k * CH) - 1u), wbits);
+    };
+    put(0);
+    put(1);
+    put(2);
+    if (__any(nch > 3u))
+      for (uint32_t k = 3; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
+    uint2 it[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) it[u] = wl[u * GPW + ln / LPC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(it[u].x), "+v"(it[u].y));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t c1 = it[u].x & 15u;  // postings in the chunk - 1
+      const float wv_ = __uint_as_float(it[u].y);
+      f.wq0[u] = 2u * lo <= c1 ? wv_ : 0.0f;
+      f.wq1[u] = 2u * lo + 1u <= c1 ? wv_ : 0.0f;
+      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, ((it[u].x ^ c1) >> 2) + lo * 8u, 0, 0);  // start * 4 B + lane
+    }
+  };
+
+  RowExt R1 = load_R(q0 + 1), R2 = load_R(q0 + 2), R3 = load_R(q0 + 3), R4 = load_R(q0 + 4);
+  TermW I3, I4;
+  Seg P2, P3;
+  WaveWork wfa, wfb, wfc;
+  {
+    const RowExt R0 = load_R(q0);
+    const TermW I0 = load_I(R0), I1 = load_I(R1), I2 = load_I(R2);
+    I3 = load_I(R3);
+    const Seg P0 = load_P(I0), P1 = load_P(I1);
+    P2 = load_P(I2);
+    __syncthreads();
+    flatten(wfa, P0, R0, 0);
+    flatten(wfb, P1, R1, 1);
+  }
+  __syncthreads();
+  n_long_next = ctr[0];
+
+  auto round = [&](WaveWork &w0, WaveWork &w2, const int q, const int l3, const int nnz_q) {
+    const int par = (q - q0) & 1;
+    // coarse threshold with the slack that covers the rounding of up to nnz_q products and the fp16 weights
+    const int thr_c = (int)a.cx_theta - (nnz_q + 1) / 2 - 2;
+    const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
+
+    const RowExt R5 = load_R(q + 5);
+    I4 = load_I(R4);
+    P3 = load_P(I3);
+    flatten(w2, P2, R2, l3 == 0 ? 2 : l3 - 1);
+
+    auto crossed = [&](const uint32_t slot, const uint32_t p, const uint32_t old16) {
+      if (thr1 - old16 < p) {
+        const uint32_t k = atomicAdd(&ctr[5 + 2 * par], 1u);
+        if (k < (uint32_t)SURVCAP) surv[k] = slot;
+      }
+    };
+    // one coarse posting: 16-bit add into the candidate's half of its word, old half back from the returning atomic
+    auto add16 = [&](const uint32_t pcw, const float wqs, uint32_t &p, uint32_t &old16) {
+      const uint32_t slot = pcw & 0xffffu;
+      const float w = __half2float(__ushort_as_half((unsigned short)(pcw >> 16)));
+      p = max((uint32_t)__builtin_fmaf(wqs, w, 0.5f), 1u);  // >= 1 so that a touch always shows (errs upward: safe)
+      const uint32_t sh = (slot & 1u) << 4;
+      const uint32_t old = atomicAdd(&acc[slot >> 1], p << sh);  // ds_add_rtn_u32; halves cannot carry (bounded scores)
+      old16 = (old >> sh) & 0xffffu;
+    };
+    auto visit = [&](const uint32_t pcw, const float wqs) {
+      uint32_t p, old16;
+      add16(pcw, wqs, p, old16);
+      my_cands += old16 == 0u ? 1u : 0u;
+      crossed(pcw & 0xffffu, p, old16);
+    };
+    {
+      uint32_t p0[U], p1[U], o0[U], o1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        p0[u] = p1[u] = 0u;
+        o0[u] = o1[u] = 1u;
+        if (w0.wq0[u] != 0.0f) add16(w0.pc[u].x, w0.wq0[u], p0[u], o0[u]);
+        if (w0.wq1[u] != 0.0f) add16(w0.pc[u].y, w0.wq1[u], p1[u], o1[u]);
+      }
+      bool any_cross = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        my_cands += (o0[u] == 0u ? 1u : 0u) + (o1[u] == 0u ? 1u : 0u);
+        any_cross |= (thr1 - o0[u] < p0[u]) | (thr1 - o1[u] < p1[u]);
+      }
+      if (any_cross) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          crossed(w0.pc[u].x & 0xffffu, p0[u], o0[u]);
+          crossed(w0.pc[u].y & 0xffffu, p1[u], o1[u]);
+        }
+      }
+    }
+    if (w0.totch > WIN) {
+      if (ln == 0) ctr[4 + 2 * par] = 1;
+      for (int c0 = WIN; c0 < w0.totch; c0 += GPW) {
+        const uint32_t c = (uint32_t)(c0 + ln / LPC);
+        uint32_t st = 0, cn = 0;
+        float wq_ = 0.f;
+        for (int m = 0; m < w0.tw; ++m) {
+          const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)w0.excl, m);
+          const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)w0.len, m);
+          const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)w0.s, m);
+          const float wm = cxs * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0.w), m));
+          const uint32_t nm = (lm + CH - 1) / CH;
+          const bool sel = c >= em && c < em + nm;
+          const uint32_t k = c - em;
+          st = sel ? sm + k * CH : st;
+          cn = sel ? min((uint32_t)CH, lm - k * CH) : cn;
+          wq_ = sel ? wm : wq_;
+        }
+        const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, st * 4u + lo * 8u, 0, 0);
+        if (2u * lo < cn) visit(two.x, wq_);
+        if (2u * lo + 1u < cn) visit(two.y, wq_);
+      }
+    }
+    const uint32_t n_long = min(n_long_next, (uint32_t)LONGCAP);
+    for (uint32_t j = 0; j < n_long; ++j) {
+      const uint2 sgm = longs[l3 * LONGCAP + j];
+      const float wq_ = cxs * long_w[l3 * LONGCAP + j];
+      for (uint32_t k = tid; k < sgm.y; k += BLOCK) visit(__builtin_amdgcn_raw_buffer_load_b32(rs_po, (sgm.x + k) * 4u, 0, 0), wq_);
+    }
+    __syncthreads();
+
+    const uint2 fl = *reinterpret_cast<const uint2 *>(&ctr[4 + 2 * par]);
+    n_long_next = ctr[l3 == 2 ? 0 : l3 + 1];
+    const uint32_t n_surv = fl.y;
+    const bool full_zero = n_long > 0 || fl.x != 0 || n_surv > (uint32_t)SURVCAP;
+    if (n_surv > 0) {
+      const int64_t qext = a.q_ext[q];
+      const unsigned short *acc16 = reinterpret_cast<const unsigned short *>(acc);
+      if (n_surv <= (uint32_t)SURVCAP) {
+        for (uint32_t i = tid; i < (n_surv + kWave - 1) / kWave * kWave; i += BLOCK) {
+          bool ok = false;
+          uint32_t c = 0;
+          if (i < n_surv) {
+            c = surv[i];
+            ok = a.ext_id[tile_row0 + c] != qext;
+          }
+          const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+          if (ok && o < a.res_cap) {
+            a.res_q[o] = q;
+            a.res_c[o] = (int32_t)(tile_row0 + c);
+            a.res_s[o] = (float)acc16[c] / cxs;  // coarse score, replaced by k_rescore
+          }
+        }
+      } else {
+        for (int i = tid; i < (cb + BLOCK - 1) / BLOCK * BLOCK; i += BLOCK) {
+          bool ok = false;
+          if (i < cb) {
+            const int64_t gs = tile_row0 + i;
+            ok = (int)acc16[i] >= max(thr_c, 1) && gs < a.n_rows && a.ext_id[gs] != qext;
+          }
+          const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+          if (ok && o < a.res_cap) {
+            a.res_q[o] = q;
+            a.res_c[o] = (int32_t)(tile_row0 + i);
+            a.res_s[o] = (float)acc16[i] / cxs;
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    if (full_zero) {
+      for (int i = tid * 4; i < cb / 2; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (w0.wq0[u] != 0.0f) acc16w[w0.pc[u].x & 0xffffu] = 0;  // ds_write_b16
+        if (w0.wq1[u] != 0.0f) acc16w[w0.pc[u].y & 0xffffu] = 0;
+      }
+    }
+    if (tid == 0) {
+      ctr[l3] = 0;
+      ctr[4 + 2 * (par ^ 1)] = 0;
+      ctr[5 + 2 * (par ^ 1)] = 0;
+    }
+    __syncthreads();
+
+    P2 = P3;
+    I3 = I4;
+    R1 = R2;
+    R2 = R3;
+    R3 = R4;
+    R4 = R5;
+  };
+  // nnz of round q is R0 of that round; track it alongside (R1 is round q+1 at the top of round q)
+  int nnz_cur = load_R(q0).nnz;
+  for (int q = q0; q < q1; q += 3) {
+    int nn = R1.nnz;
+    round(wfa, wfc, q, 0, nnz_cur);
+    nnz_cur = nn;
+    if (q + 1 >= q1) break;
+    nn = R1.nnz;
+    round(wfb, wfa, q + 1, 1, nnz_cur);
+    nnz_cur = nn;
+    if (q + 2 >= q1) break;
+    nn = R1.nnz;
+    round(wfc, wfb, q + 2, 2, nnz_cur);
+    nnz_cur = nn;
+  }
+  __syncthreads();
+  if (tid < 3) stat[tid] = 0;
+  __syncthreads();
+  atomicAdd(&stat[0], my_visits);
+  atomicAdd(&stat[1], (unsigned long long)my_cands);
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&a.counters[kCtrVisits], stat[0]);
+    atomicAdd(&a.counters[kCtrCands], stat[1]);
+  }
+}
+
+__host__ __device__ inline size_t probe_coarse_lds_bytes(int cb, int block, int u, int longcap, int survcap) {
+  return ((size_t)(cb / 2 + kWave) * 4 + (size_t)(block / kWave) * (kWave / 8) * u * 8 + 3 * (size_t)longcap * 12 +
+          (size_t)survcap * 4 + 128 + 15) / 16 * 16;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// exact pass of the two-pass join: full fp32 dot product (CU:98-117) of every pair the filter let through, then the
+// `>= theta` prune (IWA:93) with wavefront compaction into the final result list.  16 lanes per pair.
+struct RescoreArgs {
+  int64_t n_pairs;
+  const int32_t *q_row;
+  const int32_t *c_slot;
+  const int64_t *q_rowptr;
+  const int32_t *q_idx;
+  const float *q_val;
+  const int64_t *c_rowptr;
+  const int32_t *c_idx;
+  const float *c_val;
+  float theta;
+  int32_t *out_q;
+  int32_t *out_c;
+  float *out_s;
+  unsigned long long *out_count;
+};
+
+__global__ void k_rescore(RescoreArgs a) {
+  const int64_t pair = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  const bool live = pair < a.n_pairs;
+  float s = 0.f;
+  int32_t qr = 0, cs = 0;
+  if (live) {
+    qr = a.q_row[pair];
+    cs = a.c_slot[pair];
+    const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
+    const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
+    for (int64_t k = qb + gl; k < qe; k += kGroup) {
+      const int32_t t = a.q_idx[k];
+      int64_t lo = cb, hi = ce;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+      }
+      if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
+    }
+  }
+  for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
+  const bool keep = live && gl == 0 && s >= a.theta;
+  const uint64_t o = wave_append(keep, a.out_count);
+  if (keep) {
+    a.out_q[o] = qr;
+    a.out_c[o] = cs;
+    a.out_s[o] = s;
   }
 }
 

@@ -49,6 +49,7 @@ extern "C" {
 #define APSS_FLAG_NORMALIZE 4u   /* L2-normalise rows on ingest (benchmark/LoadGenerator.scala:34-37) */
 #define APSS_FLAG_FORCE_SCAN 8u  /* always use the general accumulator-scan kernel (signed weights path) */
 #define APSS_FLAG_FORCE_GENERAL 16u /* never use the per-wave speed path of the probe (test hook) */
+#define APSS_FLAG_EXACT_ACCUM 32u   /* single-pass join with exact accumulators only: no coarse filter + rescoring pass */
 
 typedef struct apss_handle apss_handle;
 
@@ -79,6 +80,8 @@ typedef struct apss_stats {
   double build_ms;          /* device time of the last insert's index build, HIP events */
   int64_t probe_launches;   /* probe kernel launches of the last call (re-runs after a result-buffer growth count) */
   int64_t hbm_bytes;        /* device bytes currently reserved by the handle */
+  int64_t filter_survivors; /* two-pass join: pairs the coarse filter passed on to exact rescoring (0: single pass) */
+  double rescore_ms;        /* two-pass join: device time of the exact rescoring kernel */
 } apss_stats;
 
 /* ---- lifetime (actor construction / stop, IWA:21-39) ---- */

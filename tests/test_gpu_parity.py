@@ -51,14 +51,16 @@ def test_kat_section33_through_abi(apss_mod):
 
 @pytest.mark.parametrize("name", ["mini_uniform_t03", "mini_zipf_t05", "mini_zipf_t08"])
 @pytest.mark.parametrize("tile_rows", [256, 1024, 0])
-@pytest.mark.parametrize("general", [False, True])
-def test_golden_fixture(apss_mod, name, tile_rows, general):
-    """both probe kernels: the per-wave speed path and the general item-list kernel"""
+@pytest.mark.parametrize("path", ["two_pass", "exact_wave", "general"])
+def test_golden_fixture(apss_mod, name, tile_rows, path):
+    """all three probe paths: coarse filter + exact rescoring (default), the single-pass exact speed kernel, and the
+    general item-list kernel"""
     from apss import _lib
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     dim, theta = int(z["dim"]), float(z["theta"])
     got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=tile_rows,
-                        flags=_lib.FLAG_FORCE_GENERAL if general else 0)
+                        flags={"two_pass": 0, "exact_wave": _lib.FLAG_EXACT_ACCUM, "general": _lib.FLAG_FORCE_GENERAL}[path])
+    assert (st["filter_survivors"] > 0) == (path == "two_pass")
     want = to_map(z["out_q"], z["out_c"], z["out_sim"])
     assert_same_pairs(got, want, theta)
     # top-k (first k by (-score, q, c)): equal sets imply equal top-k up to score ties inside 1e-5
@@ -68,14 +70,14 @@ def test_golden_fixture(apss_mod, name, tile_rows, general):
     assert st["posting_visits"] == int(visits)
 
 
-@pytest.mark.parametrize("flags_name", ["fast", "force_general", "force_scan"])
+@pytest.mark.parametrize("flags_name", ["fast", "exact_wave", "force_general", "force_scan"])
 def test_scan_path_equals_crossing_path(apss_mod, oracle, flags_name):
     from apss import _lib
     n, dim, nnz, theta = 1500, 300, 12, 0.45
     rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=21, dup_frac=0.1)
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
     got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=512,
-                        flags={"fast": 0, "force_general": _lib.FLAG_FORCE_GENERAL,
+                        flags={"fast": 0, "exact_wave": _lib.FLAG_EXACT_ACCUM, "force_general": _lib.FLAG_FORCE_GENERAL,
                                "force_scan": _lib.FLAG_FORCE_SCAN}[flags_name])
     assert len(want) > 100
     assert_same_pairs(got, want, theta)
@@ -217,7 +219,7 @@ def test_c2_shape_reduced(apss_mod, oracle):
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
     assert len(want) > 500
     from apss import _lib
-    for tr, fl in ((0, 0), (8192, 0), (0, _lib.FLAG_FORCE_GENERAL)):
+    for tr, fl in ((0, 0), (8192, 0), (0, _lib.FLAG_EXACT_ACCUM), (0, _lib.FLAG_FORCE_GENERAL)):
         got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=tr, flags=fl)
         assert_same_pairs(got, want, theta)
         assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
@@ -236,8 +238,10 @@ def test_c3_shape_properties(apss_mod):
     assert s.min() >= theta - 1e-5 and s.max() <= 1 + 1e-5
     assert max(abs(got[(q, c)] - got[(c, q)]) for (q, c) in got) <= 2e-6
     assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
-    got2, _ = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=16384)
+    from apss import _lib
+    got2, st2 = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=8192, flags=_lib.FLAG_EXACT_ACCUM)
     assert_same_pairs(got2, got, theta, tol=2e-6)
+    assert st2["candidate_pairs"] == st["candidate_pairs"] and st["filter_survivors"] >= len(got)
 
 
 def test_unbounded_norms_use_the_float_path(apss_mod, oracle):
