@@ -5,7 +5,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r01
 mkdir -p $OUT
-python3 bench.py --steps 3 --warmup 1 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+python3 bench.py --steps 5 --warmup 1 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1; echo "trace rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_write.log 2>&1; echo "write rc=$?"

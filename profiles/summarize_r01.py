@@ -52,4 +52,6 @@ out = {
     "note": "traffic = L2 <-> fabric bytes (Infinity-Cache hits are counted, see the guide): an upper bound of HBM bytes",
 }
 json.dump(out, open(os.path.join(DST, "r01_probe_traffic.json"), "w"), indent=1)
+bench["roofline"]["traffic"] = traffic  # the bench run preceded this PMC summary: quote the matching passes
+json.dump(bench, open(os.path.join(DST, "r01_bench_default.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
