@@ -1272,41 +1272,54 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
         if (k < (uint32_t)SURVCAP) surv[k] = slot;
       }
     };
-    // one coarse posting: 16-bit add into the candidate's half of its word, old half back from the returning atomic
-    auto add16 = [&](const uint32_t pcw, const float wqs, uint32_t &p, uint32_t &old16) {
+    // one coarse posting: 16-bit add into the candidate's half of its word; the returning atomic gives the old WORD
+    // (the half is extracted later, so that the round's atomics are all in flight before the first wait)
+    auto add16 = [&](const uint32_t pcw, const float wqs, uint32_t &p) -> uint32_t {
       const uint32_t slot = pcw & 0xffffu;
       const float w = __half2float(__ushort_as_half((unsigned short)(pcw >> 16)));
       p = max((uint32_t)__builtin_fmaf(wqs, w, 0.5f), 1u);  // >= 1 so that a touch always shows (errs upward: safe)
-      const uint32_t sh = (slot & 1u) << 4;
-      const uint32_t old = atomicAdd(&acc[slot >> 1], p << sh);  // ds_add_rtn_u32; halves cannot carry (bounded scores)
-      old16 = (old >> sh) & 0xffffu;
+      return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));  // ds_add_rtn_u32; halves cannot carry (bounded scores)
     };
+    auto half_of = [&](const uint32_t old_word, const uint32_t pcw) { return (old_word >> ((pcw & 1u) << 4)) & 0xffffu; };
     auto visit = [&](const uint32_t pcw, const float wqs) {
-      uint32_t p, old16;
-      add16(pcw, wqs, p, old16);
+      uint32_t p;
+      const uint32_t old16 = half_of(add16(pcw, wqs, p), pcw);
       my_cands += old16 == 0u ? 1u : 0u;
       crossed(pcw & 0xffffu, p, old16);
     };
-    {
-      uint32_t p0[U], p1[U], o0[U], o1[U];
+    // the register window, two steps (four atomics) at a time: enough LDS atomics in flight to cover their latency,
+    // few enough live registers to keep two workgroups on the CU
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        p0[u] = p1[u] = 0u;
-        o0[u] = o1[u] = 1u;
-        if (w0.wq0[u] != 0.0f) add16(w0.pc[u].x, w0.wq0[u], p0[u], o0[u]);
-        if (w0.wq1[u] != 0.0f) add16(w0.pc[u].y, w0.wq1[u], p1[u], o1[u]);
+    for (int u0 = 0; u0 < U; u0 += 2) {
+      uint32_t p0[2] = {0u, 0u}, p1[2] = {0u, 0u};
+      uint32_t o0[2] = {0xffffffffu, 0xffffffffu}, o1[2] = {0xffffffffu, 0xffffffffu};  // idle lane: never first, never crossed
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int u = u0 + j;
+        if (u < U) {
+          if (w0.wq0[u] != 0.0f) o0[j] = add16(w0.pc[u].x, w0.wq0[u], p0[j]);
+          if (w0.wq1[u] != 0.0f) o1[j] = add16(w0.pc[u].y, w0.wq1[u], p1[j]);
+        }
       }
       bool any_cross = false;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        my_cands += (o0[u] == 0u ? 1u : 0u) + (o1[u] == 0u ? 1u : 0u);
-        any_cross |= (thr1 - o0[u] < p0[u]) | (thr1 - o1[u] < p1[u]);
+      for (int j = 0; j < 2; ++j) {
+        const int u = u0 + j;
+        if (u < U) {
+          o0[j] = half_of(o0[j], w0.pc[u].x);
+          o1[j] = half_of(o1[j], w0.pc[u].y);
+          my_cands += (o0[j] == 0u ? 1u : 0u) + (o1[j] == 0u ? 1u : 0u);
+          any_cross |= (thr1 - o0[j] < p0[j]) | (thr1 - o1[j] < p1[j]);
+        }
       }
       if (any_cross) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          crossed(w0.pc[u].x & 0xffffu, p0[u], o0[u]);
-          crossed(w0.pc[u].y & 0xffffu, p1[u], o1[u]);
+        for (int j = 0; j < 2; ++j) {
+          const int u = u0 + j;
+          if (u < U) {
+            crossed(w0.pc[u].x & 0xffffu, p0[j], o0[j]);
+            crossed(w0.pc[u].y & 0xffffu, p1[j], o1[j]);
+          }
         }
       }
     }
