@@ -265,3 +265,24 @@ def test_medium_norms_use_the_coarser_fixed_point_scale(apss_mod, oracle):
     assert len(want) > 100
     got, _ = _gpu_join(apss_mod, dim, theta, rp, idx, v3, tile_rows=512)
     assert_same_pairs(got, want, theta, band=1e-4, tol=1e-4)  # inputs are fp32 on the device: 6e-8 * 9 * terms
+
+
+def test_maildir_small_plumbing(apss_mod):
+    """BASELINE config 1: TF-IDF vectors of the reference's mail corpus (HashingTF 2^20, rows of up to 2247 terms),
+    fixture from tests/golden/make_maildir_fixture.py; exercises vectorDim = 2^20 and the > 512-terms-per-query path"""
+    z = np.load(os.path.join(GOLDEN, "maildir_small_tfidf.npz"))
+    dim, theta = int(z["dim"]), float(z["theta"])
+    want = to_map(z["out_q"], z["out_c"], z["out_sim"])
+    assert dim == 1 << 20 and len(want) > 100
+    got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"])
+    assert_same_pairs(got, want, theta)
+    # streamed in three batches the union of the answers is the subset where the query arrived no earlier than the hit
+    n = len(z["rowptr"]) - 1
+    rp, idx, val = z["rowptr"], z["indices"], z["values"]
+    with apss_mod.ApssIndex(dim, theta, tile_rows=256) as ix:
+        stream = {}
+        for b0 in range(0, n, 256):
+            b1 = min(n, b0 + 256)
+            sl = slice(rp[b0], rp[b1])
+            stream.update(to_map(*ix.insert_and_query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])))
+    assert_same_pairs(stream, {k: v for k, v in want.items() if k[0] >= (k[1] // 256) * 256}, theta)
