@@ -70,7 +70,7 @@ struct apss_handle {
   bool use_coarse = false;  // build and use the coarse index (non-sharded handles without APSS_FLAG_EXACT_ACCUM)
   int64_t n_tiles = 0;      // tiles of the exact rendering (apss_stats)
   int64_t ex_built_rows = 0;     // the exact rendering covers rows [0, ex_built_rows)
-  DevBuf<float> tile_min;
+  DevBuf<float> tile_min, tile_min_c;  // shard mode: min positive sub-norm per exact / coarse tile
   // query staging (apss_query: batch not stored)
   DevBuf<int64_t> q_rowptr, q_ext;
   DevBuf<int32_t> q_idx;
@@ -273,7 +273,8 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   APSS_TRY(ensure(h, ix.seg, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
   APSS_TRY(ensure(h, ix.base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
   APSS_TRY(ensure(h, ix.total, (size_t)n_tiles, 0));
-  if (h->sharded && !ix.coarse) APSS_TRY(ensure(h, h->tile_min, (size_t)n_tiles, (size_t)tile0));
+  DevBuf<float> &tmin = ix.coarse ? h->tile_min_c : h->tile_min;
+  if (h->sharded) APSS_TRY(ensure(h, tmin, (size_t)n_tiles, (size_t)tile0));
   if (ix.h_base.empty()) ix.h_base.push_back(0);
   ix.h_base.resize((size_t)tile0 + 1);  // bases of the tiles that stay
   const int64_t r0 = tile0 * cb;
@@ -311,9 +312,9 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.post = ix.post.p;
   b.post_c = ix.post_c.p;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
-  if (h->sharded && !ix.coarse)
+  if (h->sharded)
     hipLaunchKernelGGL(k_tile_min_sub, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream,
-                       (const float *)h->sub.p, h->n_rows, (int32_t)cb, h->tile_min.p, tile0);
+                       (const float *)h->sub.p, h->n_rows, (int32_t)cb, tmin.p, tile0);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipEventSynchronize(h->ev1));
@@ -392,8 +393,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // ---- path 1: two-pass join (coarse filter + exact rescoring) ----
   const double cx_scale = bound < 1.9 ? 32768.0 : 16384.0;
   const double cx_theta = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
+  // (shard mode scales the threshold down per query and tile: the kernel clamps it at 1, which only admits more)
   const bool coarse_path = h->use_coarse && mode == 0 && bound < 3.9 && q_max_nnz <= 512 && !forced_general &&
-                           !getenv("APSS_EXACT_ACCUM") && cx_theta - (double)(q_max_nnz + 1) / 2 - 2 >= 1.0 &&
+                           !getenv("APSS_EXACT_ACCUM") && (h->sharded || cx_theta - (double)(q_max_nnz + 1) / 2 - 2 >= 1.0) &&
                            h->store_max_nnz * (int64_t)h->cx.cb + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
 
   ProbeArgs a{};
@@ -425,7 +427,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.post = h->ex.post.p;
   a.post_c = h->cx.post_c.p;
   a.tile_post_base = ix.base.p;
-  a.tile_scale = h->sharded ? h->tile_min.p : nullptr;
+  a.tile_scale = h->sharded ? (coarse_path ? h->tile_min_c.p : h->tile_min.p) : nullptr;
   a.cb = ix.cb;
   a.n_tiles = (int32_t)ix.n_tiles;
 
@@ -491,9 +493,15 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (coarse_path) {
-      auto kern = k_probe_coarse<512, 5, 128, 512>;
-      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
+      if (h->sharded) {
+        auto kern = k_probe_coarse<512, 5, 128, 512, true>;
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
+      } else {
+        auto kern = k_probe_coarse<512, 5, 128, 512, false>;
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
+      }
       HIPCHK(h, hipGetLastError());
     } else if (wave_path && getenv("APSS_DIAG")) {
       // diagnostic build: in-kernel cycle stamps per round segment (shares only; never a benchmark number)
@@ -547,7 +555,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     h->out_q = h->res_q.p;
     h->out_c = h->res_c.p;
     h->out_s = h->res_s.p;
-    if (coarse_path) {
+    if (coarse_path && !h->sharded) {
       // exact pass: re-score what the filter let through from the fp32 store and prune at theta
       const int64_t n_cand = h->n_res;
       h->st.filter_survivors = n_cand;
@@ -679,7 +687,10 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
     return APSS_E_INVALID;
   }
   h->sharded = !(h->cfg.term_lo == 0 && h->cfg.term_hi == cfg->dim);
-  h->use_coarse = !h->sharded && !(cfg->flags & (APSS_FLAG_EXACT_ACCUM | APSS_FLAG_FORCE_GENERAL | APSS_FLAG_FORCE_SCAN));
+  // term-range shards keep the single-pass kernel: their rounds carry 1/T of the postings, and at that density the
+  // coarse kernel's costlier steps lose (measured T=2: 235 ms vs 196 ms per shard); APSS_SHARD_COARSE=1 re-enables it
+  h->use_coarse = !(cfg->flags & (APSS_FLAG_EXACT_ACCUM | APSS_FLAG_FORCE_GENERAL | APSS_FLAG_FORCE_SCAN)) &&
+                  (!h->sharded || getenv("APSS_SHARD_COARSE"));
   h->cb = cfg->tile_rows ? cfg->tile_rows : 16384;
   h->ex.cb = h->cb;
   h->ex.align = kSegAlign;
@@ -740,7 +751,7 @@ void apss_destroy(apss_handle *h) {
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   release(h->rowptr); release(h->ext); release(h->idx); release(h->val); release(h->sub);
   for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); }
-  release(h->tile_min); release(h->fin_q); release(h->fin_c); release(h->fin_s);
+  release(h->tile_min); release(h->tile_min_c); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
   release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val);

@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
 // No true pair is lost: fp16 rounds a weight by at most 2^-11 relative, each product is rounded once to an
 // integer (<= 1/2 unit), integer sums are exact, so  coarse >= S*true*(1 - 2^-11) - nnz_q/2.  The survivors (a few
 // per thousand more than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.
-template <int BLOCK, int U, int LONGCAP, int SURVCAP>
+template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD>
 __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   constexpr int CH = 16;                 // postings per chunk: 8 lanes x 2 postings (8 B per lane)
@@ -1139,6 +1139,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
   const uint32_t lo = (uint32_t)(ln % LPC);  // this lane handles postings 2*lo and 2*lo + 1 of its chunk
   uint2 *wl = items + wv * WIN;
   const float cxs = a.cx_scale;
+  const float tile_scale = SHARD ? a.tile_scale[tile] : 1.0f;  // shard mode: min positive sub-norm of the tile's rows
 
   const int64_t qbase = a.q_rowptr[q0], qend = a.q_rowptr[q1];
   const int64_t pbase = a.tile_post_base[tile], pend = a.tile_post_base[tile + 1];
@@ -1258,7 +1259,11 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
   auto round = [&](WaveWork &w0, WaveWork &w2, const int q, const int l3, const int nnz_q) {
     const int par = (q - q0) & 1;
     // coarse threshold with the slack that covers the rounding of up to nnz_q products and the fp16 weights
-    const int thr_c = (int)a.cx_theta - (nnz_q + 1) / 2 - 2;
+    // shard mode: the candidate rule p_g >= theta |q_g| |c_g| with the tile's smallest |c_g| in the hot loop and the
+    // candidate's own |c_g| on the survivors; either way minus the coarse slack, so no candidate is lost
+    const float qs = SHARD ? a.q_scale[q] : 1.0f;
+    const int slack = (nnz_q + 1) / 2 + 2;
+    const int thr_c = (SHARD ? (int)floorf(a.cx_theta * qs * tile_scale) : (int)a.cx_theta) - slack;
     const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
 
     const RowExt R5 = load_R(q + 5);
@@ -1367,7 +1372,8 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
           uint32_t c = 0;
           if (i < n_surv) {
             c = surv[i];
-            ok = a.ext_id[tile_row0 + c] != qext;
+            ok = a.ext_id[tile_row0 + c] != qext &&
+                 (!SHARD || (int)acc16[c] >= (int)floorf(a.cx_theta * qs * a.c_scale[tile_row0 + c]) - slack);
           }
           const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
           if (ok && o < a.res_cap) {
@@ -1381,7 +1387,8 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
           bool ok = false;
           if (i < cb) {
             const int64_t gs = tile_row0 + i;
-            ok = (int)acc16[i] >= max(thr_c, 1) && gs < a.n_rows && a.ext_id[gs] != qext;
+            ok = (int)acc16[i] >= max(thr_c, 1) && gs < a.n_rows && a.ext_id[gs] != qext &&
+                 (!SHARD || (int)acc16[i] >= (int)floorf(a.cx_theta * qs * a.c_scale[gs]) - slack);
           }
           const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
           if (ok && o < a.res_cap) {
