@@ -76,8 +76,9 @@ class HipShardEngine:
         else:
             self.ix.insert_dev(self.s_ids, self.s_rp, self.s_idx, self.s_val)
             self.ix.query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
-        q, c, _ = self.ix.fetch()  # external ids == global row numbers
+        q, c, sc = self.ix.fetch()  # external ids == global row numbers
         self.stats = self.ix.stats()
+        self.scores = sc  # final scores when the handle holds the whole term space (T == 1)
         return (torch.from_numpy(q).to(self.device), torch.from_numpy(c).to(self.device))
 
     def partial(self, q_row, c_row):
@@ -112,9 +113,10 @@ class ShardedJoin:
 
     T term shards share a candidate range and combine their partial scores with an all-reduce inside their group
     (the exchange the term-sharded index needs); the D candidate ranges are independent (their result sets are
-    disjoint).  Term shards alone do not speed the join up much: a shard has 1/T of the posting visits of every
-    (query, tile) round but the same number of rounds, and the per-round cost is mostly fixed -- so by
-    default T = 2 whenever world >= 2 and the remaining factor goes to candidate ranges."""
+    disjoint).  Term shards do not speed this join up: a shard has 1/T of the posting visits of every (query, tile)
+    round but the same number of rounds, and a round's cost is mostly fixed (T = 2 is SLOWER
+    than one GPU) -- so the default is T = 1 (candidate ranges only, no data-path collective); `term_shards` selects
+    the term-sharded layouts with their RCCL exchange."""
 
     def __init__(self, dim, theta, rank, world, device, tile_rows=0, engine_factory=None, comm_device=None,
                  term_shards=None):
@@ -122,7 +124,7 @@ class ShardedJoin:
         # collectives run on `comm_device` tensors: the GPU itself under RCCL, the CPU when rehearsing with gloo
         self.comm = comm_device or device
         self.tile_rows = tile_rows
-        T = term_shards or (2 if world % 2 == 0 else 1)
+        T = term_shards or 1
         if world % T:
             raise ValueError("term_shards must divide the world size")
         self.T, self.D = T, world // T
@@ -161,20 +163,25 @@ class ShardedJoin:
 
     def step(self, return_pairs=False):
         q, c = self.engine.candidates()
-        key = q.to(torch.int64) * self.n + c.to(torch.int64)
-        if self.T > 1:
-            allk, sizes = self._all_gather_var(key)
+        if self.T == 1:
+            # the handle holds the whole term space: its answer for this candidate range is already exact and pruned
+            uq, uc, sizes = q, c, [int(q.numel())]
+            uniq = q
+            sc = getattr(self.engine, "scores", None)
+            part = torch.from_numpy(np.asarray(sc, dtype=np.float32)).to(self.device) if sc is not None \
+                else self.engine.partial(uq, uc)
+            keep = torch.ones(q.numel(), dtype=torch.bool, device=self.device) if sc is not None else part >= self.theta
         else:
-            allk, sizes = key, [key.numel()]
-        uniq = torch.unique(allk)  # sorted: every rank of the group sees the same order
-        uq = torch.div(uniq, self.n, rounding_mode="floor")
-        uc = uniq - uq * self.n
-        part = self.engine.partial(uq, uc)
-        if self.T > 1:
+            key = q.to(torch.int64) * self.n + c.to(torch.int64)
+            allk, sizes = self._all_gather_var(key)
+            uniq = torch.unique(allk)  # sorted: every rank of the group sees the same order
+            uq = torch.div(uniq, self.n, rounding_mode="floor")
+            uc = uniq - uq * self.n
+            part = self.engine.partial(uq, uc)
             part = part.to(self.comm)
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)  # RCCL all-reduce of partial scores
             part = part.to(self.device)
-        keep = part >= self.theta
+            keep = part >= self.theta
         st = getattr(self.engine, "stats", {}) or {}
         # whole-job counters: posting visits and touched pairs add up over all ranks; result pairs over the D groups
         mine = float(keep.sum().item()) if self.ti == 0 else 0.0

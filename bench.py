@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--n", type=int, default=None, help="override the number of vectors (debug)")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid (default 2 when --gpus is even)")
+    ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid: term-range shards per candidate range (default 1)")
     ap.add_argument("--solo", default=None, help="T,D,i,j: time shard (term i of T, rows j of D) alone on this GPU (projection)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real run) | gloo (rehearsal: all ranks share GPU 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the baseline sample")
@@ -187,8 +187,9 @@ def main():
         dist.all_reduce(pm, op=dist.ReduceOp.MAX)
         probe_ms = [float(pm.item())]  # slowest shard's probe kernel
         visits, cands, launches = sj.last["posting_visits"], int(distinct.item()), world
-        parallelism = ("%d term-range shards x %d candidate ranges; per term group: candidate all-gather + RCCL "
-                       "all-reduce of partial scores" % (sj.T, sj.D))
+        parallelism = ("%d candidate ranges, no data-path collective (term-sharded layouts: --term-shards)" % sj.D
+                       if sj.T == 1 else "%d term-range shards x %d candidate ranges; per term group: candidate "
+                       "all-gather + RCCL all-reduce of partial scores" % (sj.T, sj.D))
         extra = {"exchange": sj.last.get("exchange"), "shard_touched_pairs_sum": sj.last["candidate_pairs"],
                  "backend": a.backend}
 
