@@ -750,7 +750,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 typedef unsigned int apss_u32x2 __attribute__((ext_vector_type(2)));
 
 template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, bool DIAG = false>
-__global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
+__global__ __launch_bounds__(BLOCK, BLOCK <= 512 && U <= 5 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_wave(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   constexpr int GPW = kWave / kChunk;  // chunk groups per wave step (8)
   constexpr int WIN = GPW * U;         // chunks in one wave's register window
@@ -1110,8 +1110,10 @@ __global__ __launch_bounds__(BLOCK) void k_probe_wave(const ProbeArgs a) {
 // No true pair is lost: fp16 rounds a weight by at most 2^-11 relative, each product is rounded once to an
 // integer (<= 1/2 unit), integer sums are exact, so  coarse >= S*true*(1 - 2^-11) - nnz_q/2.  The survivors (a few
 // per thousand more than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.
+// __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
+// sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.
 template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD>
-__global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
+__global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   constexpr int CH = 16;                 // postings per chunk: 8 lanes x 2 postings (8 B per lane)
   constexpr int LPC = 8;                 // lanes per chunk
@@ -1167,7 +1169,8 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
     float w;
     int totch, tw;
     apss_u32x2 pc[U];   // two coarse postings per lane and step
-    float wq0[U], wq1[U];  // query weight x cx_scale for each of them; 0 past the chunk's end
+    float wq[U];        // query weight x cx_scale of the step's chunk
+    uint32_t act;       // bit 2u / 2u+1: the first / second posting of step u is real (inside the chunk)
   };
   auto load_R = [&](int q) {
     RowExt r;
@@ -1224,6 +1227,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
     put(2);
     if (__any(nch > 3u))
       for (uint32_t k = 3; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
+    f.act = 0;
     uint2 it[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) it[u] = wl[u * GPW + ln / LPC];
@@ -1232,9 +1236,10 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t c1 = it[u].x & 15u;  // postings in the chunk - 1
-      const float wv_ = __uint_as_float(it[u].y);
-      f.wq0[u] = 2u * lo <= c1 ? wv_ : 0.0f;
-      f.wq1[u] = 2u * lo + 1u <= c1 ? wv_ : 0.0f;
+      f.wq[u] = __uint_as_float(it[u].y);
+      const bool real = it[u].y != 0u;  // an all-zero descriptor is an empty slot of the strip
+      if (real && 2u * lo <= c1) f.act |= 1u << (2 * u);
+      if (real && 2u * lo + 1u <= c1) f.act |= 2u << (2 * u);
       f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, ((it[u].x ^ c1) >> 2) + lo * 8u, 0, 0);  // start * 4 B + lane
     }
   };
@@ -1292,23 +1297,28 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
       my_cands += old16 == 0u ? 1u : 0u;
       crossed(pcw & 0xffffu, p, old16);
     };
-    // the register window, two steps (four atomics) at a time: enough LDS atomics in flight to cover their latency,
-    // few enough live registers to keep two workgroups on the CU
+    // the register window, BATCH steps (2 x BATCH atomics) at a time: enough LDS atomics in flight to cover their
+    // latency, few enough live registers to keep two workgroups on the CU
+    constexpr int BATCH = 3;
 #pragma unroll
-    for (int u0 = 0; u0 < U; u0 += 2) {
-      uint32_t p0[2] = {0u, 0u}, p1[2] = {0u, 0u};
-      uint32_t o0[2] = {0xffffffffu, 0xffffffffu}, o1[2] = {0xffffffffu, 0xffffffffu};  // idle lane: never first, never crossed
+    for (int u0 = 0; u0 < U; u0 += BATCH) {
+      uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < BATCH; ++j) {
+        p0[j] = p1[j] = 0u;
+        o0[j] = o1[j] = 0xffffffffu;  // idle lane: never first, never crossed
+      }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
         const int u = u0 + j;
         if (u < U) {
-          if (w0.wq0[u] != 0.0f) o0[j] = add16(w0.pc[u].x, w0.wq0[u], p0[j]);
-          if (w0.wq1[u] != 0.0f) o1[j] = add16(w0.pc[u].y, w0.wq1[u], p1[j]);
+          if (w0.act & (1u << (2 * u))) o0[j] = add16(w0.pc[u].x, w0.wq[u], p0[j]);
+          if (w0.act & (2u << (2 * u))) o1[j] = add16(w0.pc[u].y, w0.wq[u], p1[j]);
         }
       }
       bool any_cross = false;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < BATCH; ++j) {
         const int u = u0 + j;
         if (u < U) {
           o0[j] = half_of(o0[j], w0.pc[u].x);
@@ -1319,7 +1329,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
       }
       if (any_cross) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < BATCH; ++j) {
           const int u = u0 + j;
           if (u < U) {
             crossed(w0.pc[u].x & 0xffffu, p0[j], o0[j]);
@@ -1407,8 +1417,8 @@ __global__ __launch_bounds__(BLOCK) void k_probe_coarse(const ProbeArgs a) {
       unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (w0.wq0[u] != 0.0f) acc16w[w0.pc[u].x & 0xffffu] = 0;  // ds_write_b16
-        if (w0.wq1[u] != 0.0f) acc16w[w0.pc[u].y & 0xffffu] = 0;
+        if (w0.act & (1u << (2 * u))) acc16w[w0.pc[u].x & 0xffffu] = 0;  // ds_write_b16
+        if (w0.act & (2u << (2 * u))) acc16w[w0.pc[u].y & 0xffffu] = 0;
       }
     }
     if (tid == 0) {

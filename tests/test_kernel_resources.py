@@ -1,0 +1,35 @@
+"""Guards the occupancy the probe kernels are designed for: two 512-thread workgroups per CU = 4 waves per SIMD
+needs <= 128 VGPRs and no scratch.  (A harmless-looking edit once tipped k_probe_coarse to 130 VGPRs: one workgroup
+per CU, 1.6x slower.)  hipcc cross-compiles for gfx950 without a GPU."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "all-pairs-similarity_amd", "csrc")
+
+
+def test_speed_kernels_keep_two_workgroups_per_cu(tmp_path):
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                          "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "k.s"),
+                          os.path.join(CSRC, "apss_hip.hip")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cur, res = None, {}
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            res[cur] = {}
+        for key in ("VGPRs", "ScratchSize \\[bytes/lane\\]", "Occupancy \\[waves/SIMD\\]", "LDS Size \\[bytes/block\\]"):
+            m = re.search(r"\s%s: (\d+)" % key, line)
+            if m and cur:
+                res[cur][key.split(" ")[0]] = int(m.group(1))
+    checked = 0
+    for name, r in res.items():
+        two_per_cu = ("k_probe_coarseILi512" in name) or ("k_probe_waveILi512ELi5" in name)
+        if two_per_cu:
+            assert r["VGPRs"] <= 128 and r["ScratchSize"] == 0 and r["Occupancy"] >= 4, (name, r)
+            checked += 1
+        if "k_probe" in name:
+            assert r["ScratchSize"] == 0, (name, r)
+    assert checked >= 4
