@@ -14,6 +14,7 @@ CONFIGS = {
     "c3": dict(n=1_000_000, dim=100_000, nnz=100, zipf_s=0.0, theta=0.8, seed=20242),
     "c3z": dict(n=1_000_000, dim=100_000, nnz=100, zipf_s=0.5, theta=0.8, seed=20242),
     "c5": dict(n=10_000_000, dim=1_000_000, nnz=200, zipf_s=0.0, theta=0.9, seed=20244),
+    "c5s": dict(n=2_000_000, dim=1_000_000, nnz=200, zipf_s=0.0, theta=0.9, seed=20244),  # C5 shape at one fifth of N
 }
 
 

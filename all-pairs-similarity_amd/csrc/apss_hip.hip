@@ -450,7 +450,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::max(1.0, std::ceil(theta * scale_used)));
   a.theta_fxi = (int32_t)std::max(-2147483647.0, std::min(2147483647.0, std::ceil(theta * scale_used)));
   const bool coarse_two = h->cx.cb <= 16384;  // small coarse tiles (tests): same shape, smaller lists
-  const size_t lds = coarse_path ? probe_coarse_lds_bytes(h->cx.cb, 512, 5, 128, 512)
+  const bool cx_big = h->cx.cb > 32768;  // experiment: one 1024-thread workgroup per CU over a 65536-row tile
+  const size_t lds = coarse_path ? (cx_big ? probe_coarse_lds_bytes(h->cx.cb, 1024, 5, 256, 1024) : probe_coarse_lds_bytes(h->cx.cb, 512, 5, 128, 512))
                      : wave_path ? probe_wave_lds_bytes(h->ex.cb, wave_block, wave_u, wave_longcap, wave_survcap)
                                  : probe_lds_bytes(h->ex.cb, kProbeBlock, mode);
   (void)coarse_two;
@@ -493,7 +494,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (coarse_path) {
-      if (h->sharded) {
+      if (cx_big) {
+        auto kern = k_probe_coarse<1024, 5, 256, 1024, false>;
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+      } else if (h->sharded) {
         auto kern = k_probe_coarse<512, 5, 128, 512, true>;
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
@@ -695,6 +700,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   h->ex.cb = h->cb;
   h->ex.align = kSegAlign;
   h->cx.cb = std::min(2 * h->cb, 32768);
+  if (getenv("APSS_CX_TILE")) h->cx.cb = atoi(getenv("APSS_CX_TILE"));  // experiment hook (multiple of 64, <= 65536)
   h->cx.align = kSegAlignC;
   h->cx.coarse = true;
   if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {

@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 && U <= 5 ? 2 * BLOCK / 256 : B
 // __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
 // sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.
 template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD>
-__global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
+__global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   constexpr int CH = 16;                 // postings per chunk: 8 lanes x 2 postings (8 B per lane)
   constexpr int LPC = 8;                 // lanes per chunk

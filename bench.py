@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", help="c2 | c3 | c3z (BASELINE.json configs; c3 is the metric's)")
+    ap.add_argument("--workload", default="c3", help="c2 | c3 | c3z | c5s | c5 (BASELINE.json configs; c3 is the metric's)")
     ap.add_argument("--n", type=int, default=None, help="override the number of vectors (debug)")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
