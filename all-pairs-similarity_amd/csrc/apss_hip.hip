@@ -338,6 +338,13 @@ int32_t ensure_exact_index(apss_handle *h) {
 int32_t build_index(apss_handle *h, int64_t row0) {
   h->st.build_ms = 0;
   if (h->use_coarse) {
+    if (h->cx.n_tiles == 0 && h->cfg.tile_rows == 0 && !getenv("APSS_CX_TILE") && h->n_rows > 0) {
+      // a round's cost is mostly fixed, so what matters is how many postings a (tile, term) segment holds:
+      // rows_per_tile * nnz_per_row / dim.  Below ~16 at 32768 rows (C5 shape: 6.5) the 65536-row tile with one
+      // 1024-thread workgroup per CU wins (C5 shape at N=2M: 647 vs 790 ms); at C3 (33) two workgroups per CU win.
+      const double seg32 = 32768.0 * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;
+      h->cx.cb = seg32 < 16.0 ? 65536 : 32768;
+    }
     APSS_TRY(build_tiles(h, h->cx, row0));
     h->st.build_ms += h->cx.build_ms;
     h->ex_built_rows = std::min(h->ex_built_rows, row0 / h->ex.cb * h->ex.cb);  // exact tiles from here on are stale

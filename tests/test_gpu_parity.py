@@ -286,3 +286,16 @@ def test_maildir_small_plumbing(apss_mod):
             sl = slice(rp[b0], rp[b1])
             stream.update(to_map(*ix.insert_and_query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])))
     assert_same_pairs(stream, {k: v for k, v in want.items() if k[0] >= (k[1] // 256) * 256}, theta)
+
+
+def test_sparse_regime_uses_65536_row_tiles(apss_mod, oracle):
+    """few postings per (tile, term) segment (C5-like density): the handle picks 65536-row coarse tiles and the
+    1024-thread filter kernel; more than one tile, the last one partial"""
+    n, dim, nnz, theta = 70_000, 40_000, 16, 0.6
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=55, dup_frac=0.05)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 1000
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val)
+    assert st["tiles"] == 2 and st["filter_survivors"] >= len(want)  # 65536 + 4464 rows
+    assert_same_pairs(got, want, theta)
+    assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
