@@ -419,7 +419,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.q_nnz_end = q_nnz_end;
   // ~2 workgroups per CU per tile in flight at once, tiles swept one after another (tile-major grid) so the
   // chip works on one tile's postings at a time and they stay in L2 / Infinity Cache
-  const int64_t want_chunks = 512;
+  const int64_t want_chunks = getenv("APSS_CHUNKS") ? atoi(getenv("APSS_CHUNKS")) : 1024;  // (env: tuning hook)
   a.q_chunk = (int32_t)std::max<int64_t>(1, ceil_div(nq, want_chunks));
   a.n_chunks = (int32_t)ceil_div(nq, a.q_chunk);
   a.q_slot_base = q_slot_base;
