@@ -1365,7 +1365,21 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     for (uint32_t j = 0; j < n_long; ++j) {
       const uint2 sgm = longs[l3 * LONGCAP + j];
       const float wq_ = cxs * long_w[l3 * LONGCAP + j];
-      for (uint32_t k = tid; k < sgm.y; k += BLOCK) visit(__builtin_amdgcn_raw_buffer_load_b32(rs_po, (sgm.x + k) * 4u, 0, 0), wq_);
+      // two postings (8 B) per lane and load, two loads in flight per lane
+      uint32_t k = 2u * tid;
+      for (; k + 2u * BLOCK < sgm.y; k += 4u * BLOCK) {
+        const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+        const apss_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2u * BLOCK) * 4u, 0, 0);
+        visit(a0.x, wq_);
+        if (k + 1u < sgm.y) visit(a0.y, wq_);
+        visit(a1.x, wq_);
+        if (k + 2u * BLOCK + 1u < sgm.y) visit(a1.y, wq_);
+      }
+      for (; k < sgm.y; k += 2u * BLOCK) {
+        const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+        visit(a0.x, wq_);
+        if (k + 1u < sgm.y) visit(a0.y, wq_);
+      }
     }
     __syncthreads();
 
