@@ -440,13 +440,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
 
   // ---- path 2: single-pass exact speed kernel (k_probe_wave); kernel shapes: A = 8 waves x 64-chunk window, one
   // workgroup per CU at 32768-row tiles; C = 8 waves x 40-chunk window, TWO workgroups per CU at <= 16384-row tiles
-  const char *var_env = getenv("APSS_WAVE_VARIANT");  // test / A-B hook
-  char variant = var_env ? var_env[0] : (h->ex.cb <= 16384 ? 'C' : 'A');
-  if (variant != 'A' && variant != 'B' && variant != 'C' && variant != 'D' && variant != 'E') variant = 'A';
-  const int wave_block = variant == 'B' ? 1024 : (variant == 'D' ? 256 : 512);
-  const int wave_u = (variant == 'A' || variant == 'D') ? 8 : 5;
-  const int wave_longcap = (variant == 'A' || variant == 'B') ? 256 : (variant == 'E' ? 64 : 128);
-  const int wave_survcap = (variant == 'A' || variant == 'B') ? 1024 : (variant == 'E' ? 256 : 512);
+  const char variant = h->ex.cb <= 16384 ? 'C' : 'A';
+  const int wave_block = 512;
+  const int wave_u = variant == 'A' ? 8 : 5;
+  const int wave_longcap = variant == 'A' ? 256 : 128;
+  const int wave_survcap = variant == 'A' ? 1024 : 512;
   // chunk descriptors pack (first posting * 8 + count - 1) into 32 bits: a tile's postings must number < 2^28
   const bool wave_path = !coarse_path && mode == 0 && fx_scale > 0 && q_max_nnz <= wave_block && !forced_general &&
                          h->store_max_nnz * (int64_t)h->ex.cb + (int64_t)kSegAlign * h->cfg.dim < (1LL << 28);
@@ -476,10 +474,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       else { if (diag) APSS_LAUNCH_WAVE1(B, UU, LC, SC, false, true); else APSS_LAUNCH_WAVE1(B, UU, LC, SC, false, false); }          \
     } while (0)
     if (variant == 'A') APSS_LAUNCH_WAVE(512, 8, 256, 1024);
-    else if (variant == 'B') APSS_LAUNCH_WAVE(1024, 5, 256, 1024);
-    else if (variant == 'C') APSS_LAUNCH_WAVE(512, 5, 128, 512);
-    else if (variant == 'E') APSS_LAUNCH_WAVE(512, 5, 64, 256);
-    else APSS_LAUNCH_WAVE(256, 8, 128, 512);
+    else APSS_LAUNCH_WAVE(512, 5, 128, 512);
 #undef APSS_LAUNCH_WAVE1
 #undef APSS_LAUNCH_WAVE
     HIPCHK(h, hipGetLastError());
