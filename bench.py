@@ -210,7 +210,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "u16+f32",  # 16-bit fixed-point filter sums, fp32 exact rescoring of the survivors
         "data": "synthetic",
         "config": {"workload": "%s: N=%d dim=%d nnz=%d %s theta=%g, single-batch self-join (build + probe)" % (
             a.workload, n, cfg["dim"], cfg["nnz"], "Zipf(%g)" % cfg["zipf_s"] if cfg["zipf_s"] else "uniform",
