@@ -79,6 +79,7 @@ struct apss_handle {
   DevBuf<int64_t> s_keep, s_cnt, s_rowdst, s_nnzdst, in_rowptr, in_ext;
   DevBuf<int32_t> in_idx;
   DevBuf<float> s_inv, s_sub, in_val;
+  DevBuf<double> in_val64;
   // results of the last query-type call
   DevBuf<int32_t> res_q, res_c, fin_q, fin_c;
   DevBuf<float> res_s, fin_s;
@@ -621,7 +622,12 @@ int32_t validate_host_csr(apss_handle *h, int64_t n, const int64_t *rowptr, cons
   return APSS_OK;
 }
 
-// host CSR (double values) -> device input staging (float values)
+// host CSR (double values, as SparkSparseVector.values) -> device input staging (float values).  The doubles are
+// copied as they are and narrowed on the device: a host-side conversion loop cost more than the extra PCIe bytes.
+__global__ void k_narrow_f64(const double *in, float *out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+
 int32_t upload(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices, const double *values,
                const int64_t *ext_ids) {
   const int64_t nnz = n ? rowptr[n] : 0;
@@ -629,17 +635,18 @@ int32_t upload(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *
   APSS_TRY(ensure(h, h->in_ext, (size_t)std::max<int64_t>(n, 1)));
   APSS_TRY(ensure(h, h->in_idx, (size_t)std::max<int64_t>(nnz, 1)));
   APSS_TRY(ensure(h, h->in_val, (size_t)std::max<int64_t>(nnz, 1)));
-  std::vector<float> f((size_t)nnz);
-  for (int64_t k = 0; k < nnz; ++k) f[(size_t)k] = (float)values[k];
+  APSS_TRY(ensure(h, h->in_val64, (size_t)std::max<int64_t>(nnz, 1)));
   if (n) {
     HIPCHK(h, hipMemcpyAsync(h->in_rowptr.p, rowptr, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->in_ext.p, ext_ids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
   }
   if (nnz) {
     HIPCHK(h, hipMemcpyAsync(h->in_idx.p, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->in_val.p, f.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->in_val64.p, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_narrow_f64, dim3(2048), dim3(256), 0, h->stream, (const double *)h->in_val64.p, h->in_val.p, nnz);
+    HIPCHK(h, hipGetLastError());
   }
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // `f` goes out of scope
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // the caller's buffers may be reused on return
   return APSS_OK;
 }
 
@@ -762,7 +769,7 @@ void apss_destroy(apss_handle *h) {
   release(h->tile_min); release(h->tile_min_c); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
-  release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val);
+  release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val); release(h->in_val64);
   release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword); release(h->dbg);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
