@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid: term-range shards per candidate range (default 1)")
     ap.add_argument("--solo", default=None, help="T,D,i,j: time shard (term i of T, rows j of D) alone on this GPU (projection)")
+    ap.add_argument("--no-term-row", action="store_true", help="skip the term-sharded comparison row of multi-GPU runs")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real run) | gloo (rehearsal: all ranks share GPU 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the baseline sample")
     return ap.parse_args()
@@ -187,11 +188,32 @@ def main():
         dist.all_reduce(pm, op=dist.ReduceOp.MAX)
         probe_ms = [float(pm.item())]  # slowest shard's probe kernel
         visits, cands, launches = sj.last["posting_visits"], int(distinct.item()), world
+        # comparison row, measured in the same run: the term-sharded layout of BASELINE.json configs[3] (T = 2 term
+        # ranges per candidate range, candidate all-gather + RCCL all-reduce of partial scores); not part of `value`
+        term_row = None
+        if world % 2 == 0 and (a.term_shards or 1) == 1 and not a.no_term_row:
+            try:
+                del sj.engine
+                torch.cuda.empty_cache()
+                sj2 = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev,
+                                  term_shards=2)
+                sj2.load(rp, idx, val)
+                sj2.step()
+                sync()
+                t1 = time.perf_counter()
+                n2 = sj2.step()
+                sync()
+                t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=comm_dev)
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                term_row = {"grid": "2 term ranges x %d candidate ranges" % (world // 2), "ms_per_step": float(t2.item()) * 1e3,
+                            "result_pairs": int(n2), "exchange": sj2.last["exchange"]}
+            except Exception as e:  # the comparison row must never take the benchmark down
+                term_row = {"error": repr(e)[:200]}
         parallelism = ("%d candidate ranges, no data-path collective (term-sharded layouts: --term-shards)" % sj.D
                        if sj.T == 1 else "%d term-range shards x %d candidate ranges; per term group: candidate "
                        "all-gather + RCCL all-reduce of partial scores" % (sj.T, sj.D))
         extra = {"exchange": sj.last.get("exchange"), "shard_touched_pairs_sum": sj.last["candidate_pairs"],
-                 "backend": a.backend}
+                 "backend": a.backend, "term_sharded_comparison": term_row}
 
     if rank != 0:
         if world > 1:
