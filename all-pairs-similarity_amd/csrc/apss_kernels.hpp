@@ -1112,11 +1112,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 && U <= 5 ? 2 * BLOCK / 256 : B
 // per thousand more than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.
 // __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
 // sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.
-template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD>
+template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16>
 __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
-  constexpr int CH = 16;                 // postings per chunk: 8 lanes x 2 postings (8 B per lane)
-  constexpr int LPC = 8;                 // lanes per chunk
+  constexpr int CH = CHUNK;              // postings per chunk: LPC lanes x 2 postings (8 B per lane)
+  constexpr int LPC = CH / 2;            // lanes per chunk
   constexpr int GPW = kWave / LPC;       // chunks per wave step
   constexpr int WIN = GPW * U;
   static_assert(WIN <= kWave, "the window strip is cleared by one store per lane");
@@ -1222,11 +1222,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       if (k < nch && excl + k < (uint32_t)WIN)
         wl[excl + k] = make_uint2((g.s + k * CH) * 16u + (min((uint32_t)CH, len - k * CH) - 1u), wbits);
     };
-    put(0);
-    put(1);
-    put(2);
-    if (__any(nch > 3u))
-      for (uint32_t k = 3; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
+    constexpr uint32_t kPuts = CH == 16 ? 3u : 5u;  // covers segments of up to 48 / 40 postings without the loop
+#pragma unroll
+    for (uint32_t k = 0; k < kPuts; ++k) put(k);
+    if (__any(nch > kPuts))
+      for (uint32_t k = kPuts; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
     f.act = 0;
     uint2 it[U];
 #pragma unroll
@@ -1476,8 +1476,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   }
 }
 
-__host__ __device__ inline size_t probe_coarse_lds_bytes(int cb, int block, int u, int longcap, int survcap) {
-  return ((size_t)(cb / 2 + kWave) * 4 + (size_t)(block / kWave) * (kWave / 8) * u * 8 + 3 * (size_t)longcap * 12 +
+__host__ __device__ inline size_t probe_coarse_lds_bytes(int cb, int block, int u, int longcap, int survcap, int chunk = 16) {
+  return ((size_t)(cb / 2 + kWave) * 4 + (size_t)(block / kWave) * (kWave / (chunk / 2)) * u * 8 + 3 * (size_t)longcap * 12 +
           (size_t)survcap * 4 + 128 + 15) / 16 * 16;
 }
 
