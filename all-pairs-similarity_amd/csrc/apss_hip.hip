@@ -80,6 +80,8 @@ struct apss_handle {
   DevBuf<int32_t> in_idx;
   DevBuf<float> s_inv, s_sub, in_val;
   DevBuf<double> in_val64;
+  DevBuf<int32_t> vq_first, vrow_q;  // virtual-row table of the last query batch (queries of > 512 terms)
+  DevBuf<int64_t> vrow_ptr, vrow_np, vrow_first;
   // results of the last query-type call
   DevBuf<int32_t> res_q, res_c, fin_q, fin_c;
   DevBuf<float> res_s, fin_s;
@@ -402,9 +404,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const double cx_scale = bound < 1.9 ? 32768.0 : 16384.0;
   const double cx_theta = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
   // (shard mode scales the threshold down per query and tile: the kernel clamps it at 1, which only admits more)
-  const bool coarse_path = h->use_coarse && mode == 0 && bound < 3.9 && q_max_nnz <= 512 && !forced_general &&
+  const bool coarse_path = h->use_coarse && mode == 0 && bound < 3.9 && !forced_general && nq < (1LL << 30) &&
+                           (q_max_nnz <= 512 || !h->sharded) &&
                            !getenv("APSS_EXACT_ACCUM") && (h->sharded || cx_theta - (double)(q_max_nnz + 1) / 2 - 2 >= 1.0) &&
-                           h->store_max_nnz * (int64_t)h->cx.cb + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
+                           std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
 
   ProbeArgs a{};
   a.seg_stride = (int64_t)h->cfg.dim;
@@ -484,6 +487,26 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     return APSS_OK;
   };
 
+  if (coarse_path && q_max_nnz > 512) {
+    // queries of more than 512 terms: cut them into parts of <= 512 terms that share the accumulators
+    APSS_TRY(ensure(h, h->vrow_np, (size_t)nq + 1));
+    APSS_TRY(ensure(h, h->vrow_first, (size_t)nq + 2));
+    APSS_TRY(ensure(h, h->vq_first, (size_t)nq + 1));
+    hipLaunchKernelGGL(k_vrow_count, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, h->stream, q_rowptr, nq, 512, h->vrow_np.p);
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->vrow_np.p, h->vrow_first.p, nq);
+    HIPCHK(h, hipGetLastError());
+    int64_t nv = 0;
+    HIPCHK(h, hipMemcpyAsync(&nv, h->vrow_first.p + nq, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    APSS_TRY(ensure(h, h->vrow_ptr, (size_t)nv + 1));
+    APSS_TRY(ensure(h, h->vrow_q, (size_t)nv + 1));
+    hipLaunchKernelGGL(k_vrow_fill, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, h->stream, q_rowptr, nq, 512,
+                       (const int64_t *)h->vrow_first.p, h->vq_first.p, h->vrow_ptr.p, h->vrow_q.p);
+    HIPCHK(h, hipGetLastError());
+    a.vq_first = h->vq_first.p;
+    a.vrow_ptr = h->vrow_ptr.p;
+    a.vrow_q = h->vrow_q.p;
+  }
   if (h->res_q.cap == 0) {
     const size_t cap0 = 1u << 20;
     APSS_TRY(ensure(h, h->res_q, cap0, 0, true));
@@ -499,7 +522,15 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (coarse_path) {
-      if (cx_big) {
+      if (a.vq_first && cx_big) {
+        auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, true>;
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+      } else if (a.vq_first) {
+        auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, true>;
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
+      } else if (cx_big) {
         auto kern = k_probe_coarse<1024, 5, 256, 1024, false>;
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
@@ -775,7 +806,7 @@ void apss_destroy(apss_handle *h) {
   release(h->tile_min); release(h->tile_min_c); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
-  release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val); release(h->in_val64);
+  release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val); release(h->in_val64); release(h->vq_first); release(h->vrow_q); release(h->vrow_ptr); release(h->vrow_np); release(h->vrow_first);
   release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword); release(h->dbg);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

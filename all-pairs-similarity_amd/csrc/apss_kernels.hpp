@@ -361,6 +361,11 @@ struct ProbeArgs {
   uint32_t theta_fx;  // ceil(theta * fx_scale), computed in double on the host
   int32_t theta_fxi;  // the same, signed (theta <= 0 allowed): k_probe<.., FX>
   const uint32_t *post_c;  // coarse postings (k_probe_coarse)
+  // virtual rows (k_probe_coarse, queries of more than 512 terms): part v covers q_idx[vrow_ptr[v] .. vrow_ptr[v+1])
+  // of query vrow_q[v]; vq_first[q] = first part of query q ([nq + 1]); all null: one part per query
+  const int32_t *vq_first;
+  const int64_t *vrow_ptr;
+  const int32_t *vrow_q;  // [nv + 1], sentinel nq at the end
   float cx_scale;          // coarse accumulator units per 1.0 (2^15 or 2^14)
   float cx_theta;          // theta * cx_scale * (1 - 2^-11 - 1e-6): the coarse threshold before the per-query slack
   // output
@@ -1101,6 +1106,32 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 && U <= 5 ? 2 * BLOCK / 256 : B
   }
 }
 
+// virtual-row table of a query batch: row r has max(1, ceil(nnz / part)) parts
+__global__ void k_vrow_count(const int64_t *rowptr, int64_t n, int part, int64_t *nparts) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) {
+    const int64_t len = rowptr[r + 1] - rowptr[r];
+    nparts[r] = len <= part ? 1 : (len + part - 1) / part;
+  }
+}
+__global__ void k_vrow_fill(const int64_t *rowptr, int64_t n, int part, const int64_t *first, int32_t *vq_first,
+                            int64_t *vrow_ptr, int32_t *vrow_q) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  if (r == n) {  // sentinels
+    vq_first[n] = (int32_t)first[n];
+    vrow_ptr[first[n]] = rowptr[n];
+    vrow_q[first[n]] = (int32_t)n;
+    return;
+  }
+  const int64_t b = rowptr[r], e = rowptr[r + 1], f = first[r], np = first[r + 1] - f;
+  vq_first[r] = (int32_t)f;
+  for (int64_t p = 0; p < np; ++p) {
+    vrow_ptr[f + p] = b + p * part < e ? b + p * part : e;
+    vrow_q[f + p] = (int32_t)r;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_probe_coarse: FILTER pass of the two-pass exact join.  Same structure as k_probe_wave, but it reads the coarse
 // index (4-B postings {u16 slot, fp16 weight}, 32 per 128-B line) and sums into 16-bit LDS accumulators (two
@@ -1112,7 +1143,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 && U <= 5 ? 2 * BLOCK / 256 : B
 // per thousand more than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.
 // __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
 // sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.
-template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16>
+template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false>
 __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   constexpr int CH = CHUNK;              // postings per chunk: LPC lanes x 2 postings (8 B per lane)
@@ -1136,6 +1167,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const int chunk = blockIdx.x % a.n_chunks;
   const int q0 = chunk * a.q_chunk;
   const int q1 = min(a.nq, q0 + a.q_chunk);
+  // rounds run over VIRTUAL rows: a query of more than BLOCK terms is cut into parts of <= BLOCK terms that share
+  // the accumulators (the adds of all parts land before the query's candidates are cleared); without a table a
+  // virtual row is a query
+  constexpr bool vrows = VROWS;  // compiled out of the common kernel: it sits at the 128-VGPR edge
+  const int v0 = vrows ? a.vq_first[q0] : q0;
+  const int v1 = vrows ? a.vq_first[q1] : q1;
+  const int nv = vrows ? a.vq_first[a.nq] : a.nq;
   const int64_t tile_row0 = (int64_t)tile * cb;
   const int kterm = ln * NW + wv;
   const uint32_t lo = (uint32_t)(ln % LPC);  // this lane handles postings 2*lo and 2*lo + 1 of its chunk
@@ -1161,7 +1199,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   uint32_t my_cands = 0;
   uint32_t n_long_next = 0;
 
-  struct RowExt { int qb; int nnz; };
+  struct RowExt { int qb; int nnz; int q; bool last; };  // part extent, its query, is it the query's last part
   struct TermW { uint32_t term; float w; bool valid; };
   struct Seg { uint32_t s, len; float w; };
   struct WaveWork {
@@ -1172,12 +1210,23 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     float wq[U];        // query weight x cx_scale of the step's chunk
     uint32_t act;       // bit 2u / 2u+1: the first / second posting of step u is real (inside the chunk)
   };
-  auto load_R = [&](int q) {
+  auto load_R = [&](int v) {
     RowExt r;
-    const int qq = min(q, a.nq - 1);
-    const int64_t b = a.q_rowptr[qq], e = a.q_rowptr[qq + 1];
+    const int vv = min(v, nv - 1);
+    int64_t b, e;
+    if (vrows) {
+      b = a.vrow_ptr[vv];
+      e = a.vrow_ptr[vv + 1];
+      r.q = a.vrow_q[vv];
+      r.last = a.vrow_q[vv + 1] != r.q;
+    } else {
+      b = a.q_rowptr[vv];
+      e = a.q_rowptr[vv + 1];
+      r.q = vv;
+      r.last = true;
+    }
     r.qb = (int)(b - qbase);
-    r.nnz = q < q1 ? (int)(e - b) : 0;
+    r.nnz = v < v1 ? (int)(e - b) : 0;
     return r;
   };
   auto load_I = [&](const RowExt &r) {
@@ -1244,12 +1293,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     }
   };
 
-  RowExt R1 = load_R(q0 + 1), R2 = load_R(q0 + 2), R3 = load_R(q0 + 3), R4 = load_R(q0 + 4);
+  RowExt R1 = load_R(v0 + 1), R2 = load_R(v0 + 2), R3 = load_R(v0 + 3), R4 = load_R(v0 + 4);
   TermW I3, I4;
   Seg P2, P3;
   WaveWork wfa, wfb, wfc;
   {
-    const RowExt R0 = load_R(q0);
+    const RowExt R0 = load_R(v0);
     const TermW I0 = load_I(R0), I1 = load_I(R1), I2 = load_I(R2);
     I3 = load_I(R3);
     const Seg P0 = load_P(I0), P1 = load_P(I1);
@@ -1261,8 +1310,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   __syncthreads();
   n_long_next = ctr[0];
 
-  auto round = [&](WaveWork &w0, WaveWork &w2, const int q, const int l3, const int nnz_q) {
-    const int par = (q - q0) & 1;
+  bool multi = false;    // the current query has earlier parts whose slots are no longer in registers
+  bool rescan = false;   // an earlier part overflowed the survivor list: scan the accumulators at the last part
+  auto round = [&](WaveWork &w0, WaveWork &w2, const int v, const int l3, const RowExt cur) {
+    const int par = (v - v0) & 1;
+    const int q = cur.q;
+    // slack for the products of the WHOLE query (all its parts add into the same sums)
+    const int nnz_q = vrows ? (int)(a.q_rowptr[q + 1] - a.q_rowptr[q]) : cur.nnz;
     // coarse threshold with the slack that covers the rounding of up to nnz_q products and the fp16 weights
     // shard mode: the candidate rule p_g >= theta |q_g| |c_g| with the tile's smallest |c_g| in the hot loop and the
     // candidate's own |c_g| on the survivors; either way minus the coarse slack, so no candidate is lost
@@ -1271,7 +1325,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     const int thr_c = (SHARD ? (int)floorf(a.cx_theta * qs * tile_scale) : (int)a.cx_theta) - slack;
     const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
 
-    const RowExt R5 = load_R(q + 5);
+    const RowExt R5 = load_R(v + 5);
     I4 = load_I(R4);
     P3 = load_P(I3);
     flatten(w2, P2, R2, l3 == 0 ? 2 : l3 - 1);
@@ -1386,11 +1440,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     const uint2 fl = *reinterpret_cast<const uint2 *>(&ctr[4 + 2 * par]);
     n_long_next = ctr[l3 == 2 ? 0 : l3 + 1];
     const uint32_t n_surv = fl.y;
-    const bool full_zero = n_long > 0 || fl.x != 0 || n_surv > (uint32_t)SURVCAP;
-    if (n_surv > 0) {
+    // a part that is not the query's last only adds; reporting and clearing wait for the last part
+    // a multi-part query reports once, at its last part, by scanning the accumulators (no duplicates across parts)
+    if (n_surv > (uint32_t)SURVCAP || multi || !cur.last) rescan = true;
+    const bool full_zero = cur.last && (multi || rescan || n_long > 0 || fl.x != 0);
+    if ((n_surv > 0 && !rescan) || (cur.last && rescan)) {
       const int64_t qext = a.q_ext[q];
       const unsigned short *acc16 = reinterpret_cast<const unsigned short *>(acc);
-      if (n_surv <= (uint32_t)SURVCAP) {
+      if (!rescan) {
         for (uint32_t i = tid; i < (n_surv + kWave - 1) / kWave * kWave; i += BLOCK) {
           bool ok = false;
           uint32_t c = 0;
@@ -1406,7 +1463,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
             a.res_s[o] = (float)acc16[c] / cxs;  // coarse score, replaced by k_rescore
           }
         }
-      } else {
+      } else if (cur.last) {
+        // some part had more crossings than the list holds: report everything at or above the threshold, once
         for (int i = tid; i < (cb + BLOCK - 1) / BLOCK * BLOCK; i += BLOCK) {
           bool ok = false;
           if (i < cb) {
@@ -1427,7 +1485,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
 
     if (full_zero) {
       for (int i = tid * 4; i < cb / 2; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
-    } else {
+    } else if (cur.last) {
       unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1435,6 +1493,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         if (w0.act & (2u << (2 * u))) acc16w[w0.pc[u].y & 0xffffu] = 0;
       }
     }
+    multi = !cur.last;  // the next part (if any) belongs to the same query
+    if (cur.last) rescan = false;
     if (tid == 0) {
       ctr[l3] = 0;
       ctr[4 + 2 * (par ^ 1)] = 0;
@@ -1449,20 +1509,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     R3 = R4;
     R4 = R5;
   };
-  // nnz of round q is R0 of that round; track it alongside (R1 is round q+1 at the top of round q)
-  int nnz_cur = load_R(q0).nnz;
-  for (int q = q0; q < q1; q += 3) {
-    int nn = R1.nnz;
-    round(wfa, wfc, q, 0, nnz_cur);
-    nnz_cur = nn;
-    if (q + 1 >= q1) break;
-    nn = R1.nnz;
-    round(wfb, wfa, q + 1, 1, nnz_cur);
-    nnz_cur = nn;
-    if (q + 2 >= q1) break;
-    nn = R1.nnz;
-    round(wfc, wfb, q + 2, 2, nnz_cur);
-    nnz_cur = nn;
+  // the extent of round v is R0 of that round; track it alongside (R1 is round v+1 at the top of round v)
+  RowExt cur = load_R(v0);
+  for (int v = v0; v < v1; v += 3) {
+    RowExt nx = R1;
+    round(wfa, wfc, v, 0, cur);
+    cur = nx;
+    if (v + 1 >= v1) break;
+    nx = R1;
+    round(wfb, wfa, v + 1, 1, cur);
+    cur = nx;
+    if (v + 2 >= v1) break;
+    nx = R1;
+    round(wfc, wfb, v + 2, 2, cur);
+    cur = nx;
   }
   __syncthreads();
   if (tid < 3) stat[tid] = 0;

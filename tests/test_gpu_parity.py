@@ -276,6 +276,7 @@ def test_maildir_small_plumbing(apss_mod):
     assert dim == 1 << 20 and len(want) > 100
     got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"])
     assert_same_pairs(got, want, theta)
+    assert st["filter_survivors"] >= len(want)  # long rows go through the two-pass join too (in parts of 512 terms)
     # streamed in three batches the union of the answers is the subset where the query arrived no earlier than the hit
     n = len(z["rowptr"]) - 1
     rp, idx, val = z["rowptr"], z["indices"], z["values"]
@@ -299,3 +300,61 @@ def test_sparse_regime_uses_65536_row_tiles(apss_mod, oracle):
     assert st["tiles"] == 2 and st["filter_survivors"] >= len(want)  # 65536 + 4464 rows
     assert_same_pairs(got, want, theta)
     assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
+
+
+def _long_rows(n, dim, seed, lo=5, hi=1800, long_frac=0.3, dup_frac=0.3):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for i in range(n):
+        if i and rng.random() < dup_frac:  # a near-copy of an earlier row: a few terms dropped, weights jittered
+            t, v = rows[int(rng.integers(0, i))]
+            keep = rng.random(t.size) < 0.97
+            if keep.sum() == 0:
+                keep[0] = True
+            t, v = t[keep], v[keep] * (1 + 0.05 * rng.standard_normal(int(keep.sum())))
+            v = np.abs(v) + 1e-3
+        else:
+            k = int(rng.integers(513, hi)) if rng.random() < long_frac else int(rng.integers(lo, 60))
+            t = np.sort(rng.choice(dim, size=min(k, dim), replace=False)).astype(np.int32)
+            v = np.abs(rng.standard_normal(t.size)) + 0.01
+        rows.append((t, v / np.sqrt((v * v).sum())))
+    rp = np.concatenate([[0], np.cumsum([r[0].size for r in rows])]).astype(np.int64)
+    return rp, np.concatenate([r[0] for r in rows]).astype(np.int32), np.concatenate([r[1] for r in rows])
+
+
+@pytest.mark.parametrize("cx_tile", [None, "65536"])
+def test_queries_longer_than_a_workgroup_use_the_two_pass_join(apss_mod, oracle, monkeypatch, cx_tile):
+    """queries of > 512 terms are cut into parts that share the accumulators; both filter kernels (512 and 1024 threads);
+    many near-copies of one long row overflow the survivor list of a part (> 512 crossings in one tile)"""
+    if cx_tile:
+        monkeypatch.setenv("APSS_CX_TILE", cx_tile)
+    n, dim, theta = 2500, 6000, 0.7
+    rp, idx, val = _long_rows(n, dim, seed=77)
+    # 700 more near-copies of row 0, made long: every one of them crosses in the same tile for each of the others
+    rng = np.random.default_rng(5)
+    t0 = np.sort(rng.choice(dim, size=1500, replace=False)).astype(np.int32)
+    v0 = np.abs(rng.standard_normal(1500)) + 0.01
+    extra_t, extra_v, extra_rp = [], [], [int(rp[-1])]
+    for _ in range(700):
+        v = v0 * (1 + 0.02 * rng.standard_normal(1500))
+        extra_t.append(t0)
+        extra_v.append(v / np.sqrt((v * v).sum()))
+        extra_rp.append(extra_rp[-1] + 1500)
+    rp = np.concatenate([rp, np.array(extra_rp[1:], np.int64)])
+    idx = np.concatenate([idx] + extra_t)
+    val = np.concatenate([val] + extra_v)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 700 * 699
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val)
+    assert st["filter_survivors"] >= len(want) > 0
+    assert_same_pairs(got, want, theta)
+    assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
+    # frozen-index queries in small batches (parts of different queries interleave inside a workgroup's chunk)
+    with apss_mod.ApssIndex(dim, theta) as ix:
+        ix.insert(np.arange(len(rp) - 1), rp, idx, val)
+        got2 = {}
+        for b0 in range(0, 600, 97):
+            b1 = min(600, b0 + 97)
+            sl = slice(rp[b0], rp[b1])
+            got2.update(to_map(*ix.query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])))
+    assert_same_pairs(got2, {k: v for k, v in want.items() if k[0] < 600}, theta)
