@@ -98,3 +98,58 @@ def workload_counts(dim, rowptr, indices):
     """Analytic work of a full self-join: (postings, posting visits = sum_t df_t^2)."""
     df = np.bincount(indices, minlength=dim).astype(np.float64)
     return int(indices.size), float((df * df).sum())
+
+
+def make_vectors_stratified_dev(n, dim, nnz, seed, device, dup_frac=0.05, block=1 << 20):
+    """Device-side generator for the configs too large to draw on the host in reasonable time (C5: 2e9 entries).
+
+    Row i draws its j-th term uniformly from stratum j = [j*w, (j+1)*w), w = dim // nnz: strictly increasing by
+    construction, df uniform over the terms, and entry j of any two rows can only collide with entry j -- so the exact
+    dot product of two rows is an ELEMENTWISE sum, which gives a full-size parity check that needs no oracle
+    (`stratified_dot`).  Planted near-duplicates as in make_vectors (10 % of the terms redrawn inside their stratum,
+    values x U(0.9, 1.1), re-normalised); sources are base rows.  Returns torch tensors
+    (rowptr int64[n+1], idx int32[n, nnz], val float32[n, nnz], src int64[n] (-1 = base row))."""
+    import torch
+    w = dim // nnz
+    assert w >= 2
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    idx = torch.empty((n, nnz), dtype=torch.int32, device=device)
+    val = torch.empty((n, nnz), dtype=torch.float32, device=device)
+    base = (torch.arange(nnz, device=device, dtype=torch.int32) * w)[None, :]
+    for r0 in range(0, n, block):
+        r1 = min(n, r0 + block)
+        idx[r0:r1] = torch.randint(0, w, (r1 - r0, nnz), generator=g, device=device, dtype=torch.int32) + base
+        v = torch.randn((r1 - r0, nnz), generator=g, device=device).abs_() + 0.05
+        val[r0:r1] = v / v.norm(dim=1, keepdim=True)
+    src = torch.full((n,), -1, dtype=torch.int64, device=device)
+    if dup_frac > 0 and n > 1:
+        is_dup = torch.rand(n, generator=g, device=device) < dup_frac
+        is_dup[0] = False
+        rows = is_dup.nonzero().flatten()
+        # source = a base (non-duplicate) row before it: draw, then walk back to the nearest base row
+        cand = (torch.rand(rows.numel(), generator=g, device=device, dtype=torch.float64) * rows.to(torch.float64)).to(torch.int64)
+        last_base = torch.where(~is_dup, torch.arange(n, device=device), torch.zeros((), dtype=torch.int64, device=device))
+        last_base = torch.cummax(last_base, 0).values  # nearest base row at or before each position (row 0 is base)
+        s = last_base[cand]
+        src[rows] = s
+        for b0 in range(0, rows.numel(), block):
+            rr, ss = rows[b0:b0 + block], s[b0:b0 + block]
+            m = rr.numel()
+            redraw = torch.rand((m, nnz), generator=g, device=device) < 0.10
+            new_t = torch.randint(0, w, (m, nnz), generator=g, device=device, dtype=torch.int32) + base
+            idx[rr] = torch.where(redraw, new_t, idx[ss])
+            v = val[ss] * (0.9 + 0.2 * torch.rand((m, nnz), generator=g, device=device))
+            val[rr] = v / v.norm(dim=1, keepdim=True)
+    rowptr = torch.arange(0, (n + 1) * nnz, nnz, dtype=torch.int64, device=device)
+    return rowptr, idx, val, src
+
+
+def stratified_dot(idx, val, a, b, block=1 << 20):
+    """exact fp32 dot products of rows a[k], b[k] of a stratified batch (entry j only meets entry j), in float64"""
+    import torch
+    out = torch.empty(a.numel(), dtype=torch.float64, device=idx.device)
+    for k0 in range(0, a.numel(), block):
+        x, y = a[k0:k0 + block], b[k0:k0 + block]
+        out[k0:k0 + block] = ((idx[x] == idx[y]) * (val[x].double() * val[y].double())).sum(dim=1)
+    return out

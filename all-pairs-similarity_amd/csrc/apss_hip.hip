@@ -507,8 +507,19 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     a.vrow_ptr = h->vrow_ptr.p;
     a.vrow_q = h->vrow_q.p;
   }
-  if (h->res_q.cap == 0) {
-    const size_t cap0 = 1u << 20;
+  // one launch sweeps a group of tiles sized for roughly 2e11 posting visits (a few hundred ms): a very large join
+  // becomes a sequence of launches of bounded duration instead of one kernel that runs for tens of seconds
+  const int64_t total_tiles = ix.n_tiles;
+  int64_t tiles_per_launch = std::max<int64_t>(1, total_tiles);
+  if (total_tiles > 0) {
+    const double per_tile = (double)q_nnz_end * ((double)h->nnz / (double)total_tiles / (double)h->cfg.dim) + 1.0;
+    tiles_per_launch = (int64_t)std::min<double>((double)total_tiles, std::max(1.0, std::floor(2e11 / per_tile)));
+    if (getenv("APSS_TILES_PER_LAUNCH")) tiles_per_launch = std::max(1, atoi(getenv("APSS_TILES_PER_LAUNCH")));  // test hook
+    tiles_per_launch = std::min<int64_t>(tiles_per_launch, std::max<int64_t>(1, 2000000000LL / std::max(1, a.n_chunks)));
+  }
+  if (h->res_q.cap < (size_t)std::min<int64_t>(2 * nq, 1LL << 28)) {
+    // room for two hits per query up front: growing means running the whole probe again
+    const size_t cap0 = (size_t)std::max<int64_t>(1 << 20, std::min<int64_t>(2 * nq, 1LL << 28));
     APSS_TRY(ensure(h, h->res_q, cap0, 0, true));
     APSS_TRY(ensure(h, h->res_c, cap0, 0, true));
     APSS_TRY(ensure(h, h->res_s, cap0, 0, true));
@@ -521,6 +532,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     a.res_cap = h->res_q.cap;
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    int64_t n_launches = 0;
+    for (int64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_launch, ++n_launches) {
+    a.tile0 = (int32_t)t0;
+    a.n_tiles = (int32_t)std::min<int64_t>(tiles_per_launch, total_tiles - t0);
     if (coarse_path) {
       if (a.vq_first && cx_big) {
         auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, true>;
@@ -574,6 +589,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       else if (mode == 1) APSS_TRY((launch_probe<1, false>(h, a, lds)));
       else APSS_TRY((launch_probe<2, false>(h, a, lds)));
     }
+    }  // tile groups
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     unsigned long long c[kCtrCount];
     HIPCHK(h, hipMemcpyAsync(c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
@@ -581,7 +597,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->st.probe_ms += ms;
-    h->st.probe_launches++;
+    h->st.probe_launches += n_launches;
     h->st.posting_visits = (int64_t)c[kCtrVisits];
     h->st.candidate_pairs = (int64_t)c[kCtrCands];
     // the speed paths count a stored query's touch of its own slot; it is not a (q, c != q) pair

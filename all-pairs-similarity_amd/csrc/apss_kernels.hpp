@@ -345,6 +345,7 @@ struct ProbeArgs {
   int64_t n_rows;
   int32_t cb;
   int32_t n_tiles;
+  int32_t tile0;                  // first tile of this launch (a long join is cut into launches of bounded duration)
   // query batch
   const int64_t *q_rowptr;  // offsets into q_idx / q_val
   const int32_t *q_idx;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
   }
   const int tid = threadIdx.x;
   const int cb = a.cb;
-  const int tile = blockIdx.x / a.n_chunks;
+  const int tile = a.tile0 + blockIdx.x / a.n_chunks;
   const int chunk = blockIdx.x % a.n_chunks;
   const int q0 = chunk * a.q_chunk;
   const int q1 = min(a.nq, q0 + a.q_chunk);
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 && U <= 5 ? 2 * BLOCK / 256 : B
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
   const int cb = a.cb;
-  const int tile = blockIdx.x / a.n_chunks;
+  const int tile = a.tile0 + blockIdx.x / a.n_chunks;
   const int chunk = blockIdx.x % a.n_chunks;
   const int q0 = chunk * a.q_chunk;
   const int q1 = min(a.nq, q0 + a.q_chunk);
@@ -1163,7 +1164,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
   const int cb = a.cb;
-  const int tile = blockIdx.x / a.n_chunks;
+  const int tile = a.tile0 + blockIdx.x / a.n_chunks;
   const int chunk = blockIdx.x % a.n_chunks;
   const int q0 = chunk * a.q_chunk;
   const int q1 = min(a.nq, q0 + a.q_chunk);

@@ -70,6 +70,21 @@ def test_golden_fixture(apss_mod, name, tile_rows, path):
     assert st["posting_visits"] == int(visits)
 
 
+@pytest.mark.parametrize("path", ["two_pass", "exact_wave", "general"])
+def test_join_cut_into_several_launches(apss_mod, monkeypatch, path):
+    """a long join runs as a sequence of launches over groups of tiles (here: one tile per launch); same pairs and
+    the same work counters as the single launch"""
+    from apss import _lib
+    monkeypatch.setenv("APSS_TILES_PER_LAUNCH", "1")
+    z = np.load(os.path.join(GOLDEN, "mini_zipf_t05.npz"))
+    dim, theta = int(z["dim"]), float(z["theta"])
+    got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=128,
+                        flags={"two_pass": 0, "exact_wave": _lib.FLAG_EXACT_ACCUM, "general": _lib.FLAG_FORCE_GENERAL}[path])
+    assert st["probe_launches"] == st["tiles"] > 3
+    assert_same_pairs(got, to_map(z["out_q"], z["out_c"], z["out_sim"]), theta)
+    assert st["posting_visits"] == int(synth.workload_counts(dim, z["rowptr"], z["indices"])[1])
+
+
 @pytest.mark.parametrize("flags_name", ["fast", "exact_wave", "force_general", "force_scan"])
 def test_scan_path_equals_crossing_path(apss_mod, oracle, flags_name):
     from apss import _lib
@@ -358,3 +373,17 @@ def test_queries_longer_than_a_workgroup_use_the_two_pass_join(apss_mod, oracle,
             sl = slice(rp[b0], rp[b1])
             got2.update(to_map(*ix.query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])))
     assert_same_pairs(got2, {k: v for k, v in want.items() if k[0] < 600}, theta)
+
+
+def test_stratified_fullsize_property_reduced():
+    """the oracle-free full-size check (profiles/fullsize_stratified.py, run at C5 = 1e7 x 200 for
+    profiles/r01_c5_full.json) at a size that takes a second: exact scores elementwise, planted pairs all found,
+    nothing else reported, posting visits == sum df^2"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fullsize_stratified", os.path.join(os.path.dirname(GOLDEN), "..", "profiles", "fullsize_stratified.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(300_000, 100_000, 50, 0.85, seed=7)
+    assert out["missing"] == 0 and out["unexpected"] == 0 and out["planted_pairs_required"] > 10_000
+    assert out["tiles"] >= 5
