@@ -311,6 +311,9 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   ix.post_used = ix.h_base.back();
   if (ix.coarse) APSS_TRY(ensure(h, ix.post_c, (size_t)ix.post_used + 64, (size_t)ix.h_base[(size_t)tile0]));
   else APSS_TRY(ensure(h, ix.post, (size_t)ix.post_used + 64, (size_t)ix.h_base[(size_t)tile0]));
+  if (ix.coarse)  // the probe reads a zero word as "no posting": clear the padding between segments
+    HIPCHK(h, hipMemsetAsync(ix.post_c.p + ix.h_base[(size_t)tile0], 0,
+                             (size_t)(ix.post_used - ix.h_base[(size_t)tile0] + 64) * sizeof(uint32_t), h->stream));
   b.tile_post_base = ix.base.p;
   b.post = ix.post.p;
   b.post_c = ix.post_c.p;
@@ -461,6 +464,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const bool coarse_two = h->cx.cb <= 16384;  // small coarse tiles (tests): same shape, smaller lists
   const bool cx_big = h->cx.cb > 32768;  // experiment: one 1024-thread workgroup per CU over a 65536-row tile
   const bool cx8 = getenv("APSS_CX_CHUNK8") != nullptr;  // experiment: 8-posting chunks, 4 steps
+  const int vrow_part = 512;
   const size_t lds = coarse_path ? (cx_big ? probe_coarse_lds_bytes(h->cx.cb, 1024, 5, 256, 1024)
                                     : cx8 ? probe_coarse_lds_bytes(h->cx.cb, 512, 4, 128, 512, 8) : probe_coarse_lds_bytes(h->cx.cb, 512, 5, 128, 512))
                      : wave_path ? probe_wave_lds_bytes(h->ex.cb, wave_block, wave_u, wave_longcap, wave_survcap)
@@ -487,12 +491,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     return APSS_OK;
   };
 
-  if (coarse_path && q_max_nnz > 512) {
-    // queries of more than 512 terms: cut them into parts of <= 512 terms that share the accumulators
+  if (coarse_path && q_max_nnz > vrow_part) {
+    // queries of more terms than a round takes: cut them into parts that share the accumulators
     APSS_TRY(ensure(h, h->vrow_np, (size_t)nq + 1));
     APSS_TRY(ensure(h, h->vrow_first, (size_t)nq + 2));
     APSS_TRY(ensure(h, h->vq_first, (size_t)nq + 1));
-    hipLaunchKernelGGL(k_vrow_count, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, h->stream, q_rowptr, nq, 512, h->vrow_np.p);
+    hipLaunchKernelGGL(k_vrow_count, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, h->stream, q_rowptr, nq, vrow_part, h->vrow_np.p);
     hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->vrow_np.p, h->vrow_first.p, nq);
     HIPCHK(h, hipGetLastError());
     int64_t nv = 0;
@@ -500,7 +504,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     HIPCHK(h, hipStreamSynchronize(h->stream));
     APSS_TRY(ensure(h, h->vrow_ptr, (size_t)nv + 1));
     APSS_TRY(ensure(h, h->vrow_q, (size_t)nv + 1));
-    hipLaunchKernelGGL(k_vrow_fill, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, h->stream, q_rowptr, nq, 512,
+    hipLaunchKernelGGL(k_vrow_fill, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, h->stream, q_rowptr, nq, vrow_part,
                        (const int64_t *)h->vrow_first.p, h->vq_first.p, h->vrow_ptr.p, h->vrow_q.p);
     HIPCHK(h, hipGetLastError());
     a.vq_first = h->vq_first.p;

@@ -232,7 +232,9 @@ constexpr int kSegAlignC = 32;  // coarse index: 32 postings of 4 B = one 128-B 
 // coarse posting: u16 slot-in-tile | fp16 weight << 16 (4 B).  Read only by the coarse filter pass; every pair it
 // lets through is re-scored from the fp32 store.
 __device__ __forceinline__ uint32_t pack_coarse(uint32_t slot, float w) {
-  return (slot & 0xffffu) | ((uint32_t)__half_as_ushort(__float2half_rn(w)) << 16);
+  // never the zero word: zero marks padding and idle lanes in the probe (a weight below fp16's range becomes its
+  // smallest subnormal, which errs upward: safe for a filter)
+  return (slot & 0xffffu) | (max((uint32_t)__half_as_ushort(__float2half_rn(w)), 1u) << 16);
 }
 
 struct BuildArgs {
@@ -740,6 +742,12 @@ __host__ __device__ inline size_t probe_wave_lds_bytes(int cb, int block, int u,
           (size_t)survcap * 4 + 128 + 15) / 16 * 16;
 }
 
+__device__ __forceinline__ int64_t uniform64(int64_t x) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)x >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // inclusive prefix sum over the 64 lanes with DPP (VALU only, no LDS round trips)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
   x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1, lanes without a source add 0
@@ -1209,7 +1217,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     int totch, tw;
     apss_u32x2 pc[U];   // two coarse postings per lane and step
     float wq[U];        // query weight x cx_scale of the step's chunk
-    uint32_t act;       // bit 2u / 2u+1: the first / second posting of step u is real (inside the chunk)
   };
   auto load_R = [&](int v) {
     RowExt r;
@@ -1277,7 +1284,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     for (uint32_t k = 0; k < kPuts; ++k) put(k);
     if (__any(nch > kPuts))
       for (uint32_t k = kPuts; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
-    f.act = 0;
     uint2 it[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) it[u] = wl[u * GPW + ln / LPC];
@@ -1285,12 +1291,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     for (int u = 0; u < U; ++u) asm volatile("" : "+v"(it[u].x), "+v"(it[u].y));
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t c1 = it[u].x & 15u;  // postings in the chunk - 1
+      // a posting word of zero is no posting: the padding after a segment's last posting is zero-filled by the build,
+      // and an empty slot of the strip (all-zero descriptor) reads out of range, which returns zero
       f.wq[u] = __uint_as_float(it[u].y);
-      const bool real = it[u].y != 0u;  // an all-zero descriptor is an empty slot of the strip
-      if (real && 2u * lo <= c1) f.act |= 1u << (2 * u);
-      if (real && 2u * lo + 1u <= c1) f.act |= 2u << (2 * u);
-      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, ((it[u].x ^ c1) >> 2) + lo * 8u, 0, 0);  // start * 4 B + lane
+      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, it[u].y != 0u ? ((it[u].x >> 4) << 2) + lo * 8u : kOob, 0, 0);
     }
   };
 
@@ -1367,8 +1371,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       for (int j = 0; j < BATCH; ++j) {
         const int u = u0 + j;
         if (u < U) {
-          if (w0.act & (1u << (2 * u))) o0[j] = add16(w0.pc[u].x, w0.wq[u], p0[j]);
-          if (w0.act & (2u << (2 * u))) o1[j] = add16(w0.pc[u].y, w0.wq[u], p1[j]);
+          if (w0.pc[u].x) o0[j] = add16(w0.pc[u].x, w0.wq[u], p0[j]);
+          if (w0.pc[u].y) o1[j] = add16(w0.pc[u].y, w0.wq[u], p1[j]);
         }
       }
       bool any_cross = false;
@@ -1490,8 +1494,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (w0.act & (1u << (2 * u))) acc16w[w0.pc[u].x & 0xffffu] = 0;  // ds_write_b16
-        if (w0.act & (2u << (2 * u))) acc16w[w0.pc[u].y & 0xffffu] = 0;
+        if (w0.pc[u].x) acc16w[w0.pc[u].x & 0xffffu] = 0;  // ds_write_b16
+        if (w0.pc[u].y) acc16w[w0.pc[u].y & 0xffffu] = 0;
       }
     }
     multi = !cur.last;  // the next part (if any) belongs to the same query
@@ -1541,6 +1545,7 @@ __host__ __device__ inline size_t probe_coarse_lds_bytes(int cb, int block, int 
   return ((size_t)(cb / 2 + kWave) * 4 + (size_t)(block / kWave) * (kWave / (chunk / 2)) * u * 8 + 3 * (size_t)longcap * 12 +
           (size_t)survcap * 4 + 128 + 15) / 16 * 16;
 }
+
 
 // ---------------------------------------------------------------------------------------------------------
 // exact pass of the two-pass join: full fp32 dot product (CU:98-117) of every pair the filter let through, then the
