@@ -294,6 +294,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.seg_stride = stride;
   b.coarse = ix.coarse ? 1 : 0;
   b.seg_align = ix.align;
+  b.coarse_shift = ix.coarse && ix.cb <= 32768 ? 1 : 0;  // must agree with k_probe_coarse's SLOT2 (the 512-thread kernels)
   const int threads = 256;
   const int64_t blocks = ceil_div((h->n_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));

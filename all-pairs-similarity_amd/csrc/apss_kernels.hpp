@@ -229,8 +229,9 @@ __global__ __launch_bounds__(1024) void k_scan_i64(const int64_t *in, int64_t *o
 constexpr int kSegAlign = 16;   // exact index: 16 postings of 8 B = one 128-B line
 constexpr int kSegAlignC = 32;  // coarse index: 32 postings of 4 B = one 128-B line
 
-// coarse posting: u16 slot-in-tile | fp16 weight << 16 (4 B).  Read only by the coarse filter pass; every pair it
-// lets through is re-scored from the fp32 store.
+// coarse posting: u16 slot field | fp16 weight << 16 (4 B).  Read only by the coarse filter pass; every pair it
+// lets through is re-scored from the fp32 store.  In tiles of <= 32768 rows the slot field holds slot * 2 = the LDS byte
+// offset of the candidate's 16-bit accumulator (one AND gives the atomic's word address, one shift its half).
 __device__ __forceinline__ uint32_t pack_coarse(uint32_t slot, float w) {
   // never the zero word: zero marks padding and idle lanes in the probe (a weight below fp16's range becomes its
   // smallest subnormal, which errs upward: safe for a filter)
@@ -250,6 +251,7 @@ struct BuildArgs {
   Posting *post;                  // exact format (8 B) ...
   uint32_t *post_c;               // ... or coarse format (4 B), when `coarse`
   int32_t coarse;
+  int32_t coarse_shift;           // 1: the slot field holds slot * 2, the byte offset of the 16-bit accumulator (tiles <= 32768 rows)
   int32_t seg_align;              // postings per aligned unit (kSegAlign / kSegAlignC)
 };
 
@@ -303,7 +305,7 @@ __global__ void k_tile_scatter(BuildArgs a) {
     const int32_t t = a.idx[k];
     const uint32_t pos = sg[t].x + atomicAdd(&sg[t].y, 1u);
     if (a.coarse) {
-      a.post_c[pbase + pos] = pack_coarse(local, a.val[k]);
+      a.post_c[pbase + pos] = pack_coarse(local << a.coarse_shift, a.val[k]);
     } else {
       Posting p;
       p.slot = local;
@@ -1155,6 +1157,7 @@ __global__ void k_vrow_fill(const int64_t *rowptr, int64_t n, int part, const in
 template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false>
 __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
+  constexpr bool SLOT2 = BLOCK <= 512;    // tiles of <= 32768 rows: the posting's slot field is slot * 2 (see pack_coarse)
   constexpr int CH = CHUNK;              // postings per chunk: LPC lanes x 2 postings (8 B per lane)
   constexpr int LPC = CH / 2;            // lanes per chunk
   constexpr int GPW = kWave / LPC;       // chunks per wave step
@@ -1343,18 +1346,24 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     };
     // one coarse posting: 16-bit add into the candidate's half of its word; the returning atomic gives the old WORD
     // (the half is extracted later, so that the round's atomics are all in flight before the first wait)
+    auto slot_of = [&](const uint32_t pcw) { return SLOT2 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu; };
     auto add16 = [&](const uint32_t pcw, const float wqs, uint32_t &p) -> uint32_t {
-      const uint32_t slot = pcw & 0xffffu;
       const float w = __half2float(__ushort_as_half((unsigned short)(pcw >> 16)));
       p = max((uint32_t)__builtin_fmaf(wqs, w, 0.5f), 1u);  // >= 1 so that a touch always shows (errs upward: safe)
-      return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));  // ds_add_rtn_u32; halves cannot carry (bounded scores)
+      // ds_add_rtn_u32 on the word that holds the candidate's half; halves cannot carry (bounded scores)
+      if (SLOT2) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw & 0xfffcu)), p << ((pcw << 3) & 31u));
+      const uint32_t slot = pcw & 0xffffu;
+      return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));
     };
-    auto half_of = [&](const uint32_t old_word, const uint32_t pcw) { return (old_word >> ((pcw & 1u) << 4)) & 0xffffu; };
+    auto half_of = [&](const uint32_t old_word, const uint32_t pcw) {
+      // SLOT2: bit 1 of the slot field selects the half; v_bfe_u32 takes the offset modulo 32 and bit 0 is clear
+      return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, 16u) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
+    };
     auto visit = [&](const uint32_t pcw, const float wqs) {
       uint32_t p;
       const uint32_t old16 = half_of(add16(pcw, wqs, p), pcw);
       my_cands += old16 == 0u ? 1u : 0u;
-      crossed(pcw & 0xffffu, p, old16);
+      crossed(slot_of(pcw), p, old16);
     };
     // the register window, BATCH steps (2 x BATCH atomics) at a time: enough LDS atomics in flight to cover their
     // latency, few enough live registers to keep two workgroups on the CU
@@ -1391,8 +1400,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         for (int j = 0; j < BATCH; ++j) {
           const int u = u0 + j;
           if (u < U) {
-            crossed(w0.pc[u].x & 0xffffu, p0[j], o0[j]);
-            crossed(w0.pc[u].y & 0xffffu, p1[j], o1[j]);
+            crossed(slot_of(w0.pc[u].x), p0[j], o0[j]);
+            crossed(slot_of(w0.pc[u].y), p1[j], o1[j]);
           }
         }
       }
@@ -1494,8 +1503,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (w0.pc[u].x) acc16w[w0.pc[u].x & 0xffffu] = 0;  // ds_write_b16
-        if (w0.pc[u].y) acc16w[w0.pc[u].y & 0xffffu] = 0;
+        if (SLOT2) {
+          if (w0.pc[u].x) *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].x & 0xffffu)) = 0;  // ds_write_b16
+          if (w0.pc[u].y) *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].y & 0xffffu)) = 0;
+        } else {
+          if (w0.pc[u].x) acc16w[w0.pc[u].x & 0xffffu] = 0;
+          if (w0.pc[u].y) acc16w[w0.pc[u].y & 0xffffu] = 0;
+        }
       }
     }
     multi = !cur.last;  // the next part (if any) belongs to the same query
