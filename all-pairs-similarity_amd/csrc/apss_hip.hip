@@ -405,12 +405,14 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const bool forced_general = (h->cfg.flags & APSS_FLAG_FORCE_GENERAL) || getenv("APSS_FORCE_GENERAL");
 
   // ---- path 1: two-pass join (coarse filter + exact rescoring) ----
-  const double cx_scale = bound < 1.9 ? 32768.0 : 16384.0;
+  // accumulator units per 1.0: a 16-bit sum holds S * |q||c| (fp16 weights: + 2^-11) plus one unit per shared term
+  const double cx_room = 65535.0 - (double)std::min<int64_t>(q_max_nnz, h->store_max_nnz);
+  const double cx_scale = bound * 1.0005 * 32768.0 < cx_room ? 32768.0 : (bound * 1.0005 * 16384.0 < cx_room ? 16384.0 : 0.0);
   const double cx_theta = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
   // (shard mode scales the threshold down per query and tile: the kernel clamps it at 1, which only admits more)
   const bool coarse_path = h->use_coarse && mode == 0 && bound < 3.9 && !forced_general && nq < (1LL << 30) &&
                            (q_max_nnz <= 512 || !h->sharded) &&
-                           !getenv("APSS_EXACT_ACCUM") && (h->sharded || cx_theta - (double)(q_max_nnz + 1) / 2 - 2 >= 1.0) &&
+                           !getenv("APSS_EXACT_ACCUM") && cx_scale > 0 && (h->sharded || cx_theta - 2 >= 1.0) &&
                            std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
 
   ProbeArgs a{};

@@ -1148,10 +1148,11 @@ __global__ void k_vrow_fill(const int64_t *rowptr, int64_t n, int part, const in
 // index (4-B postings {u16 slot, fp16 weight}, 32 per 128-B line) and sums into 16-bit LDS accumulators (two
 // candidates per 32-bit word), so a tile holds 32768 candidates in 64 KB: half the (query, tile) rounds of the exact
 // kernel at two workgroups per CU, and about half the memory-side bytes per posting visit.
-// It reports every pair whose coarse sum reaches  floor(theta*S*(1 - 2^-11 - 1e-6)) - ceil(nnz_q/2) - 2  (S = cx_scale).
-// No true pair is lost: fp16 rounds a weight by at most 2^-11 relative, each product is rounded once to an
-// integer (<= 1/2 unit), integer sums are exact, so  coarse >= S*true*(1 - 2^-11) - nnz_q/2.  The survivors (a few
-// per thousand more than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.
+// It reports every pair whose coarse sum reaches  floor(theta*S*(1 - 2^-11 - 1e-6)) - 2  (S = cx_scale).
+// No true pair is lost: fp16 rounds a weight by at most 2^-11 relative, each product is rounded UP to an integer
+// (floor(x) + 1), integer sums are exact, so  coarse >= S*true*(1 - 2^-11).  The survivors (a few per thousand more
+// than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.  A sum exceeds S*q.c by at
+// most one unit per shared term; the host picks S so that S*|q||c| + min(nnz_q, nnz_c) stays below 2^16 (no carry).
 // __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
 // sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.
 template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false>
@@ -1208,7 +1209,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   for (int i = tid * 4; i < cb / 2 + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 16) ctr[tid] = 0;
   unsigned long long my_visits = 0;
-  uint32_t my_cands = 0;
+  uint32_t wave_cands = 0;  // first touches seen by this wave (uniform: counted with ballots on the scalar unit)
   uint32_t n_long_next = 0;
 
   struct RowExt { int qb; int nnz; int q; bool last; };  // part extent, its query, is it the query's last part
@@ -1323,13 +1324,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   auto round = [&](WaveWork &w0, WaveWork &w2, const int v, const int l3, const RowExt cur) {
     const int par = (v - v0) & 1;
     const int q = cur.q;
-    // slack for the products of the WHOLE query (all its parts add into the same sums)
-    const int nnz_q = vrows ? (int)(a.q_rowptr[q + 1] - a.q_rowptr[q]) : cur.nnz;
-    // coarse threshold with the slack that covers the rounding of up to nnz_q products and the fp16 weights
-    // shard mode: the candidate rule p_g >= theta |q_g| |c_g| with the tile's smallest |c_g| in the hot loop and the
-    // candidate's own |c_g| on the survivors; either way minus the coarse slack, so no candidate is lost
+    // coarse threshold: products are rounded UP (add16), so a coarse sum is never below S * sum(q_i * fp16(c_i)); the 2
+    // units cover the fp32 rounding of the scaled query weight.  Shard mode: the candidate rule p_g >= theta |q_g| |c_g|
+    // with the tile's smallest |c_g| in the hot loop and the candidate's own |c_g| on the survivors.
     const float qs = SHARD ? a.q_scale[q] : 1.0f;
-    const int slack = (nnz_q + 1) / 2 + 2;
+    constexpr int slack = 2;
     const int thr_c = (SHARD ? (int)floorf(a.cx_theta * qs * tile_scale) : (int)a.cx_theta) - slack;
     const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
 
@@ -1349,7 +1348,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     auto slot_of = [&](const uint32_t pcw) { return SLOT2 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu; };
     auto add16 = [&](const uint32_t pcw, const float wqs, uint32_t &p) -> uint32_t {
       const float w = __half2float(__ushort_as_half((unsigned short)(pcw >> 16)));
-      p = max((uint32_t)__builtin_fmaf(wqs, w, 0.5f), 1u);  // >= 1 so that a touch always shows (errs upward: safe)
+      p = (uint32_t)__builtin_fmaf(wqs, w, 1.0f);  // floor(x) + 1: never below the product, and >= 1 so that a touch shows
       // ds_add_rtn_u32 on the word that holds the candidate's half; halves cannot carry (bounded scores)
       if (SLOT2) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw & 0xfffcu)), p << ((pcw << 3) & 31u));
       const uint32_t slot = pcw & 0xffffu;
@@ -1362,7 +1361,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     auto visit = [&](const uint32_t pcw, const float wqs) {
       uint32_t p;
       const uint32_t old16 = half_of(add16(pcw, wqs, p), pcw);
-      my_cands += old16 == 0u ? 1u : 0u;
+      wave_cands += (uint32_t)__popcll(__ballot(old16 == 0u));
       crossed(slot_of(pcw), p, old16);
     };
     // the register window, BATCH steps (2 x BATCH atomics) at a time: enough LDS atomics in flight to cover their
@@ -1391,7 +1390,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         if (u < U) {
           o0[j] = half_of(o0[j], w0.pc[u].x);
           o1[j] = half_of(o1[j], w0.pc[u].y);
-          my_cands += (o0[j] == 0u ? 1u : 0u) + (o1[j] == 0u ? 1u : 0u);
+          wave_cands += (uint32_t)__popcll(__ballot(o0[j] == 0u)) + (uint32_t)__popcll(__ballot(o1[j] == 0u));
           any_cross |= (thr1 - o0[j] < p0[j]) | (thr1 - o1[j] < p1[j]);
         }
       }
@@ -1547,7 +1546,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   if (tid < 3) stat[tid] = 0;
   __syncthreads();
   atomicAdd(&stat[0], my_visits);
-  atomicAdd(&stat[1], (unsigned long long)my_cands);
+  if (ln == 0) atomicAdd(&stat[1], (unsigned long long)wave_cands);
   __syncthreads();
   if (tid == 0) {
     atomicAdd(&a.counters[kCtrVisits], stat[0]);
