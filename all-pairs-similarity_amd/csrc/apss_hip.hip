@@ -412,7 +412,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // (shard mode scales the threshold down per query and tile: the kernel clamps it at 1, which only admits more)
   const bool coarse_path = h->use_coarse && mode == 0 && bound < 3.9 && !forced_general && nq < (1LL << 30) &&
                            (q_max_nnz <= 512 || !h->sharded) &&
-                           !getenv("APSS_EXACT_ACCUM") && cx_scale > 0 && (h->sharded || cx_theta - 2 >= 1.0) &&
+                           !getenv("APSS_EXACT_ACCUM") && cx_scale > 0 && cx_theta < 65000.0 && (h->sharded || cx_theta - 2 >= 1.0) &&
                            std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
 
   ProbeArgs a{};

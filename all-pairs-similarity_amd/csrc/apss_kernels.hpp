@@ -1346,10 +1346,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     // one coarse posting: 16-bit add into the candidate's half of its word; the returning atomic gives the old WORD
     // (the half is extracted later, so that the round's atomics are all in flight before the first wait)
     auto slot_of = [&](const uint32_t pcw) { return SLOT2 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu; };
-    auto add16 = [&](const uint32_t pcw, const float wqs, uint32_t &p) -> uint32_t {
-      const float w = __half2float(__ushort_as_half((unsigned short)(pcw >> 16)));
-      p = (uint32_t)__builtin_fmaf(wqs, w, 1.0f);  // floor(x) + 1: never below the product, and >= 1 so that a touch shows
-      // ds_add_rtn_u32 on the word that holds the candidate's half; halves cannot carry (bounded scores)
+    // the product of one posting, rounded up: floor(x) + 1 is never below x and >= 1, so that a touch always shows
+    auto prod = [&](const uint32_t pcw, const float wqs) {
+      return (uint32_t)__builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(pcw >> 16))), 1.0f);
+    };
+    // ds_add_rtn_u32 on the word that holds the candidate's half; halves cannot carry (bounded scores)
+    auto add16 = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
       if (SLOT2) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw & 0xfffcu)), p << ((pcw << 3) & 31u));
       const uint32_t slot = pcw & 0xffffu;
       return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));
@@ -1359,8 +1361,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, 16u) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
     };
     auto visit = [&](const uint32_t pcw, const float wqs) {
-      uint32_t p;
-      const uint32_t old16 = half_of(add16(pcw, wqs, p), pcw);
+      const uint32_t p = prod(pcw, wqs);
+      const uint32_t old16 = half_of(add16(pcw, p), pcw);
       wave_cands += (uint32_t)__popcll(__ballot(old16 == 0u));
       crossed(slot_of(pcw), p, old16);
     };
@@ -1370,17 +1372,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
 #pragma unroll
     for (int u0 = 0; u0 < U; u0 += BATCH) {
       uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        p0[j] = p1[j] = 0u;
-        o0[j] = o1[j] = 0xffffffffu;  // idle lane: never first, never crossed
-      }
+      // an idle lane (zero word) skips only the atomic; its "old value" thr1 + 1 is never a first touch (not 0) and
+      // never a crossing (thr1 - old wraps to 2^32 - 1), whatever its p
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         const int u = u0 + j;
         if (u < U) {
-          if (w0.pc[u].x) o0[j] = add16(w0.pc[u].x, w0.wq[u], p0[j]);
-          if (w0.pc[u].y) o1[j] = add16(w0.pc[u].y, w0.wq[u], p1[j]);
+          p0[j] = prod(w0.pc[u].x, w0.wq[u]);
+          p1[j] = prod(w0.pc[u].y, w0.wq[u]);
+          o0[j] = o1[j] = thr1 + 1u;
+          if (w0.pc[u].x) o0[j] = add16(w0.pc[u].x, p0[j]);
+          if (w0.pc[u].y) o1[j] = add16(w0.pc[u].y, p1[j]);
         }
       }
       bool any_cross = false;
