@@ -468,8 +468,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const bool cx_big = h->cx.cb > 32768;  // experiment: one 1024-thread workgroup per CU over a 65536-row tile
   const bool cx8 = getenv("APSS_CX_CHUNK8") != nullptr;  // experiment: 8-posting chunks, 4 steps
   const int vrow_part = 512;
-  const size_t lds = coarse_path ? (cx_big ? probe_coarse_lds_bytes(h->cx.cb, 1024, 5, 256, 1024)
-                                    : cx8 ? probe_coarse_lds_bytes(h->cx.cb, 512, 4, 128, 512, 8) : probe_coarse_lds_bytes(h->cx.cb, 512, 5, 128, 512))
+  // (the filter kernels keep their LDS in static arrays: no dynamic allocation)
+  const size_t lds = coarse_path ? 0
                      : wave_path ? probe_wave_lds_bytes(h->ex.cb, wave_block, wave_u, wave_longcap, wave_survcap)
                                  : probe_lds_bytes(h->ex.cb, kProbeBlock, mode);
   (void)coarse_two;
@@ -546,27 +546,21 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     if (coarse_path) {
       if (a.vq_first && cx_big) {
         auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, true>;
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
       } else if (a.vq_first) {
         auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, true>;
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
       } else if (cx_big) {
         auto kern = k_probe_coarse<1024, 5, 256, 1024, false>;
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
       } else if (cx8 && !h->sharded) {
         auto kern = k_probe_coarse<512, 4, 128, 512, false, 8>;
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
       } else if (h->sharded) {
         auto kern = k_probe_coarse<512, 5, 128, 512, true>;
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
       } else {
         auto kern = k_probe_coarse<512, 5, 128, 512, false>;
-        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
       }
       HIPCHK(h, hipGetLastError());

@@ -1164,14 +1164,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   constexpr int GPW = kWave / LPC;       // chunks per wave step
   constexpr int WIN = GPW * U;
   static_assert(WIN <= kWave, "the window strip is cleared by one store per lane");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint32_t *acc = (uint32_t *)smem_raw;                   // [cb / 2] words, two u16 accumulators each (+ slack)
-  uint2 *items = (uint2 *)(acc + a.cb / 2 + kWave);       // [NW][WIN] {first posting * 16 + (count - 1), weight bits}
-  uint2 *longs = (uint2 *)(items + NW * WIN);             // [3][LONGCAP]
-  float *long_w = (float *)(longs + 3 * LONGCAP);         // [3][LONGCAP]
-  uint32_t *surv = (uint32_t *)(long_w + 3 * LONGCAP);    // [SURVCAP]
-  uint32_t *ctr = surv + SURVCAP;
-  unsigned long long *stat = reinterpret_cast<unsigned long long *>(ctr + 8);
+  // STATIC LDS (sized for the largest tile this instantiation serves): the compiler then knows every LDS address and
+  // folds the array bases into the instructions' offset fields; through a dynamic `extern __shared__` base every LDS
+  // access of the hot loop paid a VALU add of the (link-time) base.
+  constexpr int CBMAX = BLOCK <= 512 ? 32768 : 65536;
+  __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / 2 + kWave];  // two u16 accumulators per word (+ slack)
+  __shared__ uint2 items[NW * WIN];        // [NW][WIN] {first posting * 16 + (count - 1), weight bits}
+  __shared__ uint2 longs[3 * LONGCAP];     // [3][LONGCAP]
+  __shared__ float long_w[3 * LONGCAP];    // [3][LONGCAP]
+  __shared__ uint32_t surv[SURVCAP];
+  __shared__ uint32_t ctr[16];
+  __shared__ unsigned long long stat[4];
+  unsigned char *const smem_raw = reinterpret_cast<unsigned char *>(acc);
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
@@ -1556,10 +1560,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   }
 }
 
-__host__ __device__ inline size_t probe_coarse_lds_bytes(int cb, int block, int u, int longcap, int survcap, int chunk = 16) {
-  return ((size_t)(cb / 2 + kWave) * 4 + (size_t)(block / kWave) * (kWave / (chunk / 2)) * u * 8 + 3 * (size_t)longcap * 12 +
-          (size_t)survcap * 4 + 128 + 15) / 16 * 16;
-}
 
 
 // ---------------------------------------------------------------------------------------------------------
