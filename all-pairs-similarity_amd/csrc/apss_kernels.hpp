@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // access of the hot loop paid a VALU add of the (link-time) base.
   constexpr int CBMAX = BLOCK <= 512 ? 32768 : 65536;
   __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / 2 + kWave];  // two u16 accumulators per word (+ slack)
-  __shared__ uint2 items[NW * WIN];        // [NW][WIN] {first posting * 16 + (count - 1), weight bits}
+  __shared__ uint2 items[NW * WIN];        // [NW][WIN] {byte offset of the chunk's first posting, weight bits}
   __shared__ uint2 longs[3 * LONGCAP];     // [3][LONGCAP]
   __shared__ float long_w[3 * LONGCAP];    // [3][LONGCAP]
   __shared__ uint32_t surv[SURVCAP];
@@ -1209,6 +1209,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const __amdgpu_buffer_rsrc_t rs_po =
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.post_c + pbase), 0, (int)((pend - pbase) * 4), 0x00020000);
   constexpr uint32_t kOob = 0xfffffff0u;
+  constexpr uint32_t kOobStrip = 0xffffff00u;  // + lane offset (< 64 B) stays far outside every posting buffer
 
   for (int i = tid * 4; i < cb / 2 + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 16) ctr[tid] = 0;
@@ -1281,11 +1282,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     f.w = g.w;
     f.tw = wv < r.nnz ? (r.nnz - wv + NW - 1) / NW : 0;
     f.totch = __builtin_amdgcn_readlane((int)incl, kWave - 1);
-    if (ln < WIN) wl[ln] = make_uint2(0u, 0u);
+    if (ln < WIN) wl[ln] = make_uint2(kOobStrip, 0u);  // empty slot: its posting load is out of range and returns zero
     const uint32_t wbits = __float_as_uint(cxs * g.w);
     auto put = [&](const uint32_t k) {
       if (k < nch && excl + k < (uint32_t)WIN)
-        wl[excl + k] = make_uint2((g.s + k * CH) * 16u + (min((uint32_t)CH, len - k * CH) - 1u), wbits);
+        wl[excl + k] = make_uint2((g.s + k * CH) * 4u, wbits);  // {byte offset of the chunk's first posting, weight bits}
     };
     constexpr uint32_t kPuts = CH == 16 ? 3u : 5u;  // covers segments of up to 48 / 40 postings without the loop
 #pragma unroll
@@ -1302,7 +1303,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       // a posting word of zero is no posting: the padding after a segment's last posting is zero-filled by the build,
       // and an empty slot of the strip (all-zero descriptor) reads out of range, which returns zero
       f.wq[u] = __uint_as_float(it[u].y);
-      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, it[u].y != 0u ? ((it[u].x >> 4) << 2) + lo * 8u : kOob, 0, 0);
+      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, it[u].x + lo * 8u, 0, 0);
     }
   };
 
