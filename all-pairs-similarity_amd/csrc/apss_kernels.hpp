@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // a posting word of zero is no posting: the padding after a segment's last posting is zero-filled by the build,
-      // and an empty slot of the strip (all-zero descriptor) reads out of range, which returns zero
+      // and an empty slot of the strip holds an out-of-range offset, which reads as zero
       f.wq[u] = __uint_as_float(it[u].y);
       f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, it[u].x + lo * 8u, 0, 0);
     }
@@ -1509,12 +1509,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        // unconditional: an idle lane (zero word) clears slot 0, which is zero at the end of a query either way
         if (SLOT2) {
-          if (w0.pc[u].x) *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].x & 0xffffu)) = 0;  // ds_write_b16
-          if (w0.pc[u].y) *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].y & 0xffffu)) = 0;
+          *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].x & 0xffffu)) = 0;  // ds_write_b16
+          *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].y & 0xffffu)) = 0;
         } else {
-          if (w0.pc[u].x) acc16w[w0.pc[u].x & 0xffffu] = 0;
-          if (w0.pc[u].y) acc16w[w0.pc[u].y & 0xffffu] = 0;
+          acc16w[w0.pc[u].x & 0xffffu] = 0;
+          acc16w[w0.pc[u].y & 0xffffu] = 0;
         }
       }
     }
