@@ -1214,7 +1214,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   for (int i = tid * 4; i < cb / 2 + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 16) ctr[tid] = 0;
   unsigned long long my_visits = 0;
-  uint32_t wave_cands = 0;  // first touches seen by this wave (uniform: counted with ballots on the scalar unit)
+  uint32_t wave_cands = 0;  // first touches of the register window (uniform control flow: ballots on the scalar unit)
+  uint32_t my_cands = 0;    // first touches of the sweeps (divergent control flow: per lane)
   uint32_t n_long_next = 0;
 
   struct RowExt { int qb; int nnz; int q; bool last; };  // part extent, its query, is it the query's last part
@@ -1368,7 +1369,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     auto visit = [&](const uint32_t pcw, const float wqs) {
       const uint32_t p = prod(pcw, wqs);
       const uint32_t old16 = half_of(add16(pcw, p), pcw);
-      wave_cands += (uint32_t)__popcll(__ballot(old16 == 0u));
+      my_cands += old16 == 0u ? 1u : 0u;
       crossed(slot_of(pcw), p, old16);
     };
     // the register window, BATCH steps (2 x BATCH atomics) at a time: enough LDS atomics in flight to cover their
@@ -1554,7 +1555,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   if (tid < 3) stat[tid] = 0;
   __syncthreads();
   atomicAdd(&stat[0], my_visits);
-  if (ln == 0) atomicAdd(&stat[1], (unsigned long long)wave_cands);
+  atomicAdd(&stat[1], (unsigned long long)my_cands + (ln == 0 ? wave_cands : 0u));
   __syncthreads();
   if (tid == 0) {
     atomicAdd(&a.counters[kCtrVisits], stat[0]);

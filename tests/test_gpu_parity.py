@@ -387,3 +387,21 @@ def test_stratified_fullsize_property_reduced():
     out = mod.run(300_000, 100_000, 50, 0.85, seed=7)
     assert out["missing"] == 0 and out["unexpected"] == 0 and out["planted_pairs_required"] > 10_000
     assert out["tiles"] >= 5
+
+
+@pytest.mark.parametrize("hook", [None, "APSS_CX_CHUNK8", "APSS_CX_U3"])
+def test_candidate_pair_count_is_exact_when_the_window_overflows(apss_mod, monkeypatch, hook):
+    """`candidate_pairs` (the benchmark's unit) against an independent count, scipy's boolean X X^T, at C3's segment
+    density (33 postings per (tile, term)); the hooks shrink the register window so that most rounds take the
+    overflow path (first touches are then counted per lane, not per wave)"""
+    import scipy.sparse as sp
+    if hook:
+        monkeypatch.setenv(hook, "1")
+    n, dim, nnz, theta = 33_000, 100_000, 100, 0.7
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=3, dup_frac=0.05)
+    X = sp.csr_matrix((np.ones(idx.size, np.float32), idx, rp), shape=(n, dim))
+    truth = (X @ X.T).nnz - n
+    _, st = _gpu_join(apss_mod, dim, theta, rp, idx, val)
+    assert st["candidate_pairs"] == truth
+    assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
+    assert st["filter_survivors"] >= st["result_pairs"] > 1000
