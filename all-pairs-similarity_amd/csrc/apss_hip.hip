@@ -758,10 +758,10 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
     return APSS_E_INVALID;
   }
   h->sharded = !(h->cfg.term_lo == 0 && h->cfg.term_hi == cfg->dim);
-  // term-range shards keep the single-pass kernel: their rounds carry 1/T of the postings, and at that density the
-  // coarse kernel's costlier steps lose (measured T=2: 235 ms vs 196 ms per shard); APSS_SHARD_COARSE=1 re-enables it
+  // term-range shards use the coarse filter too (measured T=2: 130 ms vs 195 ms per shard with the single-pass kernel);
+  // their survivors are the shard's candidates, scored exactly in phase 2.  APSS_SHARD_EXACT=1: single-pass kernel.
   h->use_coarse = !(cfg->flags & (APSS_FLAG_EXACT_ACCUM | APSS_FLAG_FORCE_GENERAL | APSS_FLAG_FORCE_SCAN)) &&
-                  (!h->sharded || getenv("APSS_SHARD_COARSE"));
+                  (!h->sharded || !getenv("APSS_SHARD_EXACT"));
   h->cb = cfg->tile_rows ? cfg->tile_rows : 16384;
   h->ex.cb = h->cb;
   h->ex.align = kSegAlign;

@@ -9,9 +9,12 @@ from helpers import assert_same_pairs, to_map
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("shard_kernel", ["coarse_filter", "single_pass"])
 @pytest.mark.parametrize("world,zipf,theta", [(2, 0.0, 0.5), (4, 1.0, 0.6), (8, 0.0, 0.8)])
-def test_shards_on_one_gpu_match_oracle(oracle, world, zipf, theta):
+def test_shards_on_one_gpu_match_oracle(oracle, monkeypatch, world, zipf, theta, shard_kernel):
     import torch
+    if shard_kernel == "single_pass":
+        monkeypatch.setenv("APSS_SHARD_EXACT", "1")  # read when the handle is created
     from apss.dist import HipShardEngine, join_shards_local, term_ranges
     n, dim, nnz = 4000, 2000, 30
     rp, idx, val = synth.make_vectors(n, dim, nnz, zipf, seed=91, dup_frac=0.1)
