@@ -350,7 +350,7 @@ int32_t build_index(apss_handle *h, int64_t row0) {
       // rows_per_tile * nnz_per_row / dim.  Below ~16 at 32768 rows (C5 shape: 6.5) the 65536-row tile with one
       // 1024-thread workgroup per CU wins (C5 shape at N=2M: 647 vs 790 ms); at C3 (33) two workgroups per CU win.
       const double seg32 = 32768.0 * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;
-      h->cx.cb = seg32 < 16.0 ? 65536 : 32768;
+      h->cx.cb = seg32 < 16.0 && !h->sharded ? 65536 : 32768;  // (the 1024-thread kernel has no shard variant)
     }
     APSS_TRY(build_tiles(h, h->cx, row0));
     h->st.build_ms += h->cx.build_ms;
@@ -411,6 +411,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const double cx_theta = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
   // (shard mode scales the threshold down per query and tile: the kernel clamps it at 1, which only admits more)
   const bool coarse_path = h->use_coarse && mode == 0 && bound < 3.9 && !forced_general && nq < (1LL << 30) &&
+                           !(h->sharded && h->cx.cb > 32768) &&
                            (q_max_nnz <= 512 || !h->sharded) &&
                            !getenv("APSS_EXACT_ACCUM") && cx_scale > 0 && cx_theta < 65000.0 && (h->sharded || cx_theta - 2 >= 1.0) &&
                            std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);

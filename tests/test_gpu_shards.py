@@ -54,3 +54,21 @@ def test_candidate_range_shard_on_one_gpu(oracle):
         assert all(r0 <= x < r1 for x in c)
         got.update(to_map(q, c, s))
     assert_same_pairs(got, want, theta)
+
+
+def test_sparse_term_shards_keep_the_shard_threshold(oracle):
+    """few postings per (tile, term) segment: an unsharded handle would switch to 65536-row tiles and the 1024-thread
+    filter kernel, which has no shard variant (it once ran with the unsharded threshold and found nothing)"""
+    import torch
+    from apss.dist import HipShardEngine, join_shards_local, term_ranges
+    n, dim, nnz, theta = 70_000, 40_000, 16, 0.6
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=55, dup_frac=0.05)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 1000
+    dev = torch.device("cuda", 0)
+    engines = [HipShardEngine(dim, theta, tr, dev) for tr in term_ranges(np.bincount(idx, minlength=dim), 4)]
+    for e in engines:
+        e.load(rp, idx, val)
+    q, c, s, n_cand = join_shards_local(engines, n, theta)
+    assert min(n_cand) > 0
+    assert_same_pairs(to_map(q, c, s), want, theta)
