@@ -114,8 +114,8 @@ class ShardedJoin:
     T term shards share a candidate range and combine their partial scores with an all-reduce inside their group
     (the exchange the term-sharded index needs); the D candidate ranges are independent (their result sets are
     disjoint).  Term shards do not speed this join up: a shard has 1/T of the posting visits of every (query, tile)
-    round but the same number of rounds, and a round's cost is mostly fixed (T = 2 is SLOWER
-    than one GPU) -- so the default is T = 1 (candidate ranges only, no data-path collective); `term_shards` selects
+    round but the same number of rounds, and a round's cost is mostly fixed (a T = 2 shard takes as long
+    as the whole join on one GPU) -- so the default is T = 1 (candidate ranges only, no data-path collective); `term_shards` selects
     the term-sharded layouts with their RCCL exchange."""
 
     def __init__(self, dim, theta, rank, world, device, tile_rows=0, engine_factory=None, comm_device=None,
