@@ -303,7 +303,9 @@ __global__ void k_tile_scatter(BuildArgs a) {
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
   for (int64_t k = b + lane; k < e; k += kWave) {
     const int32_t t = a.idx[k];
-    const uint32_t pos = sg[t].x + atomicAdd(&sg[t].y, 1u);
+    // one 64-bit returning atomic on {start, cursor}: bumps the cursor (high word) and brings the start along
+    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(&sg[t]), 1ull << 32);
+    const uint32_t pos = (uint32_t)old + (uint32_t)(old >> 32);
     if (a.coarse) {
       a.post_c[pbase + pos] = pack_coarse(local << a.coarse_shift, a.val[k]);
     } else {
