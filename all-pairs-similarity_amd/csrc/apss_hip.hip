@@ -193,7 +193,8 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   a.flags_out = h->flagword.p;
   const int threads = 256;
   const int64_t blocks = ceil_div(n * kGroup, threads);
-  hipLaunchKernelGGL(k_ingest_count<kGroup>, dim3((unsigned)blocks), dim3(threads), 0, h->stream, a);
+  // (the workgroups loop over their rows: few workgroups = few same-address atomics on the batch summaries)
+  hipLaunchKernelGGL(k_ingest_count<kGroup>, dim3((unsigned)std::min<int64_t>(blocks, 4096)), dim3(threads), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
 
   // destination

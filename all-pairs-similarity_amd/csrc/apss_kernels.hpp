@@ -73,8 +73,15 @@ struct IngestArgs {
 // one G-lane group per row (G = 16 for short rows, 64 for rows of about a hundred entries)
 template <int G>
 __global__ void k_ingest_count(IngestArgs a) {
-  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  // per-batch summaries: combined inside the workgroup (LDS atomics) over ALL the rows it loops over, then ONE global
+  // atomic each per workgroup -- same-address global atomics are serialised at the memory side (a million of them were
+  // 4x the cost of everything else here, 250k still most of it)
+  __shared__ unsigned sh[4];
+  if (threadIdx.x < 4) sh[threadIdx.x] = 0;
+  __syncthreads();
   const int gl = threadIdx.x % G;
+  const int64_t rows_per_sweep = (int64_t)gridDim.x * (blockDim.x / G);
+  for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; row - threadIdx.x / G < a.n; row += rows_per_sweep) {
   int64_t b = 0, e = 0;
   if (row < a.n) {
     b = a.rowptr[row];
@@ -85,22 +92,10 @@ __global__ void k_ingest_count(IngestArgs a) {
     bad |= 1;
     b = e = 0;
   }
-  float sumsq = 0.f;
-  for (int64_t k = b + gl; k < e; k += G) {
-    const float v = a.val[k];
-    const int32_t t = a.idx[k];
-    if (!(t >= 0 && t < a.dim) || (k > b && a.idx[k - 1] >= t)) bad |= 1;  // SV:75 strictly increasing, < size
-    if (!isfinite(v)) bad |= 2;
-    sumsq += v * v;
-  }
-  for (int o = G / 2; o; o >>= 1) sumsq += __shfl_xor(sumsq, o, G);
-  // LG:35-37: values / sqrt(foldLeft(sum + v*v))
-  const float inv = (a.flags & 4u) ? (sumsq > 0.f ? 1.0f / sqrtf(sumsq) : 0.f) : 1.0f;
-  float sum = 0.f, sub = 0.f;
+  const bool normalise = (a.flags & 4u) != 0;  // without it one pass over the row does everything
+  float sumsq = 0.f, sum = 0.f, sub = 0.f;
   int cnt = 0;
-  for (int64_t k = b + gl; k < e; k += G) {
-    const float v = a.val[k] * inv;
-    const int32_t t = a.idx[k];
+  auto account = [&](const float v, const int32_t t) {
     sum += v;  // EPA:89 with max-weight 1.0
     const bool keep = (!(a.flags & 1u) || v > a.index_threshold) && t >= a.term_lo && t < a.term_hi;  // WWA:192
     if (keep) {
@@ -108,6 +103,20 @@ __global__ void k_ingest_count(IngestArgs a) {
       sub += v * v;
       if (v < 0.f) bad |= 4;
     }
+  };
+  for (int64_t k = b + gl; k < e; k += G) {
+    const float v = a.val[k];
+    const int32_t t = a.idx[k];
+    if (!(t >= 0 && t < a.dim) || (k > b && a.idx[k - 1] >= t)) bad |= 1;  // SV:75 strictly increasing, < size
+    if (!isfinite(v)) bad |= 2;
+    sumsq += v * v;
+    if (!normalise) account(v, t);
+  }
+  float inv = 1.0f;
+  if (normalise) {
+    for (int o = G / 2; o; o >>= 1) sumsq += __shfl_xor(sumsq, o, G);
+    inv = sumsq > 0.f ? 1.0f / sqrtf(sumsq) : 0.f;  // LG:35-37: values / sqrt(foldLeft(sum + v*v))
+    for (int64_t k = b + gl; k < e; k += G) account(a.val[k] * inv, a.idx[k]);
   }
   for (int o = G / 2; o; o >>= 1) {
     sum += __shfl_xor(sum, o, G);
@@ -115,11 +124,6 @@ __global__ void k_ingest_count(IngestArgs a) {
     cnt += __shfl_xor(cnt, o, G);
     bad |= __shfl_xor(bad, o, G);
   }
-  // per-batch summaries: combine inside the workgroup (LDS atomics), then ONE global atomic each per workgroup --
-  // a million same-address global atomics were 4x the cost of everything else in this kernel
-  __shared__ unsigned sh[4];
-  if (threadIdx.x < 4) sh[threadIdx.x] = 0;
-  __syncthreads();
   if (gl == 0 && row < a.n) {
     const bool admit = !(a.flags & 2u) || sum >= a.theta;  // EPA:89
     a.row_keep[row] = admit ? 1 : 0;
@@ -133,6 +137,7 @@ __global__ void k_ingest_count(IngestArgs a) {
       if (cnt > 0) atomicAdd(&sh[3], 1u);       // rows with at least one kept entry
     }
   }
+  }  // rows of this workgroup
   __syncthreads();
   if (threadIdx.x == 0) {
     if (sh[0]) atomicOr(a.flags_out, sh[0]);
