@@ -1,6 +1,8 @@
 // cpslab_host.cpp -- see cpslab_host.hpp.  Pure host code over the C ABI (include/apss.h); links libapss_hip.so.
 #include "cpslab_host.hpp"
 
+#include <fstream>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -47,6 +49,65 @@ SparseVector SparseVector::fromString(const std::string &s) {
   while (std::getline(vs, tok, ',')) if (!tok.empty()) v.values.push_back(std::stod(tok));
   if (v.indices.size() != v.values.size()) throw std::invalid_argument("requirement failed");
   return v;
+}
+
+std::pair<std::string, SparkSparseVector> CCWEBVideoLoadGenerator::lineParser(const std::string &line) {
+  // line.replace("(", "").replace(")", "").replace("[", "").replace("]", "").split(",")  (CCW:11-12); String.split drops
+  // trailing empty strings
+  std::string t;
+  for (char ch : line)
+    if (ch != '(' && ch != ')' && ch != '[' && ch != ']') t.push_back(ch);
+  std::vector<std::string> f;
+  size_t b = 0;
+  for (;;) {
+    const size_t e = t.find(',', b);
+    f.push_back(t.substr(b, e == std::string::npos ? e : e - b));
+    if (e == std::string::npos) break;
+    b = e + 1;
+  }
+  while (!f.empty() && f.back().empty()) f.pop_back();
+  if (f.size() < 2) throw std::invalid_argument("CC_WEB_VIDEO line without id and size: " + line);
+  auto to_int = [&](const std::string &s) {
+    size_t used = 0;
+    int v = 0;
+    try { v = std::stoi(s, &used); } catch (const std::exception &) { used = std::string::npos; }
+    if (used != s.size() || s.empty()) throw std::invalid_argument("not an Int: '" + s + "'");
+    return v;
+  };
+  auto to_double = [&](const std::string &s) {
+    size_t used = 0;
+    double v = 0;
+    try { v = std::stod(s, &used); } catch (const std::exception &) { used = std::string::npos; }
+    if (used != s.size() || s.empty()) throw std::invalid_argument("not a Double: '" + s + "'");
+    return v;
+  };
+  const int size = to_int(f[1]);  // propertyArray(1).toInt
+  if (size < 0) throw std::invalid_argument("negative vector size");
+  // propertyArray.takeRight(vectorSize): the last `size` fields (all of them when there are fewer -- allValues(i) then
+  // fails for i past the end, CCW:17)
+  if ((size_t)size > f.size()) throw std::invalid_argument("fewer than `size` values: " + line);
+  std::vector<int32_t> idx;
+  std::vector<double> val;
+  for (int i = 0; i < size; ++i) {
+    const double v = to_double(f[f.size() - (size_t)size + (size_t)i]);
+    if (v != 0) {  // allValues(_) != 0
+      idx.push_back(i);
+      val.push_back(v);
+    }
+  }
+  return {f[0], SparseVector(size, std::move(idx), std::move(val))};
+}
+
+std::vector<std::pair<std::string, SparkSparseVector>> CCWEBVideoLoadGenerator::generateVectors() const {
+  std::ifstream in(path_);
+  if (!in) throw std::runtime_error("cannot open " + path_);  // Source.fromFile: FileNotFoundException
+  std::vector<std::pair<std::string, SparkSparseVector>> out;
+  std::string line;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    out.push_back(lineParser(line));
+  }
+  return out;
 }
 
 std::string SimilarityOutput::toString() const {  // Message.scala:23-34

@@ -34,6 +34,22 @@ struct SparseVector {
 };
 using SparkSparseVector = SparseVector;  // org.apache.spark.mllib.linalg.SparseVector is used as the same struct
 
+// benchmark/CCWEBVideoLoadGenerator.scala:8-30 -- the load generator of the CC_WEB_VIDEO feature dump: one
+// "(id,(size,[...],[v0,...,v{size-1}]))"-shaped line per video; the LAST `size` comma-separated fields are the dense
+// feature values, zeros are dropped (CCW:15-20).  Feeds ClientConnection.insertNewVector.
+class CCWEBVideoLoadGenerator {
+ public:
+  explicit CCWEBVideoLoadGenerator(std::string path) : path_(std::move(path)) {}
+  // private def lineParser(line: String): (String, SparkSparseVector), CCW:10-21; throws std::invalid_argument where the
+  // reference throws NumberFormatException / IndexOutOfBounds
+  static std::pair<std::string, SparkSparseVector> lineParser(const std::string &line);
+  // def generateVectors: List[(String, SparkSparseVector)], CCW:23-29
+  std::vector<std::pair<std::string, SparkSparseVector>> generateVectors() const;
+
+ private:
+  std::string path_;
+};
+
 struct VectorIOMsg { std::vector<std::pair<std::string, SparkSparseVector>> vectors; };  // Message.scala:13
 struct IndexData { std::vector<std::pair<std::string, SparseVector>> vectors; };         // Message.scala:18 (wrappers' payload)
 struct Test { std::string content; };                                                    // Message.scala:37

@@ -243,6 +243,41 @@ def print_sparse_vector(size, indices, values):
     return buf.value.decode()
 
 
+def ccweb_line_parser(line):
+    """CCWEBVideoLoadGenerator.lineParser (core/src/main/scala/cpslab/benchmark/CCWEBVideoLoadGenerator.scala:10-21),
+    restated: strip every ( ) [ ], split on ",", field 0 = video id, field 1 = vector size, the LAST `size` fields = the
+    dense values, zeros dropped.  Returns (id, size, indices int32[], values float64[]); raises ValueError where the
+    reference throws (NumberFormatException / ArrayIndexOutOfBoundsException)."""
+    for ch in "()[]":
+        line = line.replace(ch, "")
+    f = line.split(",")
+    while f and f[-1] == "":  # java.lang.String.split drops trailing empty strings
+        f.pop()
+    if len(f) < 2:
+        raise ValueError("no id and size")
+    size = _java_int(f[1])
+    if size < 0 or size > len(f):  # takeRight gives fewer values than allIndices has entries: allValues(i) fails
+        raise ValueError("fewer than `size` values")
+    dense = np.array([_java_double(x) for x in f[len(f) - size:]], np.float64) if size else np.zeros(0)
+    nz = np.nonzero(dense != 0)[0]
+    return f[0], size, nz.astype(np.int32), dense[nz]
+
+
+def _java_int(s):
+    if not s or not (s.lstrip("+-").isdigit() and s.isascii()) or s in "+-":
+        raise ValueError("not an Int: %r" % s)
+    return int(s)
+
+
+def _java_double(s):
+    try:
+        if not s or s != s.strip():  # (Double.parseDouble trims; fields of this format never carry blanks)
+            raise ValueError
+        return float(s)
+    except ValueError:
+        raise ValueError("not a Double: %r" % s)
+
+
 def selfjoin_sample(variant, dim, theta, rowptr, indices, values, q_begin, q_end, n_threads):
     """CPU baseline: returns dict(pairs, cand_pairs, visits, seconds)."""
     rowptr, indices, values = _csr(rowptr, indices, values)

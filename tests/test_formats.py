@@ -1,0 +1,102 @@
+"""Data formats on the input side of the path, CPU only: the C++ host mirror's parsers against the
+oracle's restatement of the reference functions, on known-answer lines and on seeded random ones.
+  CCWEBVideoLoadGenerator.lineParser  core/src/main/scala/cpslab/benchmark/CCWEBVideoLoadGenerator.scala:10-21
+  Vectors.fromString / toString       core/src/main/scala/cpslab/vector/SparseVector.scala:132-141, 204-205"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "all-pairs-similarity_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def host_formats():
+    if not os.path.exists(os.path.join(ROOT, "all-pairs-similarity_amd", "csrc", "libapss_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    subprocess.check_call(["make", "-C", HOST, "host_formats"], stdout=subprocess.DEVNULL)
+
+    def run(mode, lines):
+        out = subprocess.run([os.path.join(HOST, "host_formats"), mode], input="\n".join(lines) + "\n",
+                             capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        return out.stdout.splitlines()
+    return run
+
+
+def _fmt(size, idx, val, oracle):
+    return oracle.print_sparse_vector(size, idx, val)
+
+
+KAT = [
+    # (line, expected (id, size, indices, values) or None where the reference throws)
+    ("(vid7,(4,[0,1,2,3],[0.5,0.0,2.0,0.0]))", ("vid7", 4, [0, 2], [0.5, 2.0])),
+    ("(a,(3,[0,1,2],[0,0,0]))", ("a", 3, [], [])),
+    ("(b,(2,[0,1],[1e-3,-4]))", ("b", 2, [0, 1], [0.001, -4.0])),
+    # takeRight(size) counts from the END of the line: with too few value fields it reaches back into size / id
+    ("(v1,3,1.0,2.0)", ("v1", 3, [0, 1, 2], [3.0, 1.0, 2.0])),
+    ("v9,2,0,0", ("v9", 2, [], [])),
+    ("(z,(0,[],[]))", ("z", 0, [], [])),
+    ("bad", None),
+    ("(x,(2,[0,1],[1.5,oops]))", None),
+    ("(y,(two,[0],[1.0]))", None),
+    ("(w,(5,[0],[1.0]))", None),  # size 5 but only 4 fields: allValues(4) is out of bounds
+]
+
+
+def test_ccweb_line_parser_kat(host_formats, oracle):
+    got = host_formats("ccweb", [k[0] for k in KAT])
+    assert len(got) == len(KAT)
+    for (line, want), g in zip(KAT, got):
+        if want is None:
+            assert g == "ERROR", (line, g)
+            with pytest.raises(ValueError):
+                oracle.ccweb_line_parser(line)
+            continue
+        vid, size, idx, val = oracle.ccweb_line_parser(line)
+        assert (vid, size, list(idx), list(val)) == want, line
+        gid, gvec = g.split("\t")
+        assert gid == vid
+        s2, i2, v2 = oracle.parse_sparse_vector(gvec) if size and len(idx) else (size, [], [])
+        assert s2 == size and list(i2) == list(idx) and np.allclose(v2, val, rtol=0, atol=0), (line, g)
+
+
+def test_ccweb_random_lines_and_file(host_formats, oracle, tmp_path):
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(200):
+        size = int(rng.integers(1, 40))
+        dense = np.where(rng.random(size) < 0.5, 0.0, np.round(rng.standard_normal(size), 6))
+        lines.append("(vid%d,(%d,[%s],[%s]))" % (i, size, ",".join(str(j) for j in range(size)),
+                                                 ",".join(repr(float(x)) for x in dense)))
+    got = host_formats("ccweb", lines)
+    p = tmp_path / "cc_web_video.txt"
+    p.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([os.path.join(HOST, "host_formats"), "ccweb-file", str(p)], capture_output=True, text=True)
+    assert out.stdout.splitlines() == got  # generateVectors == lineParser per line, in file order
+    for line, g in zip(lines, got):
+        vid, size, idx, val = oracle.ccweb_line_parser(line)
+        gid, gvec = g.split("\t")
+        assert gid == vid
+        if len(idx):
+            s2, i2, v2 = oracle.parse_sparse_vector(gvec)
+            assert s2 == size and list(i2) == list(idx) and list(v2) == list(val)
+        else:
+            assert gvec == "(%d,[],[])" % size
+
+
+def test_sparse_vector_text_round_trip(host_formats, oracle):
+    lines = ["(10,[1,4,7],[0.5,0.25,2.0])", "(1048576,[0,1048575],[1.0E-5,3.0])", "(3,[2],[-1.5])", "(3,[0,1],[1.0])x,[",
+             "nonsense"]
+    got = host_formats("vector", lines)
+    for line, g in zip(lines, got):
+        try:
+            size, idx, val = oracle.parse_sparse_vector(line)
+        except ValueError:
+            assert g == "ERROR", line
+            continue
+        s2, i2, v2 = oracle.parse_sparse_vector(g)
+        assert (s2, list(i2), list(v2)) == (size, list(idx), list(val))
