@@ -15,6 +15,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,6 +42,7 @@ def parse():
     ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid: term-range shards per candidate range (default 1)")
     ap.add_argument("--solo", default=None, help="T,D,i,j: time shard (term i of T, rows j of D) alone on this GPU (projection)")
     ap.add_argument("--no-term-row", action="store_true", help="skip the term-sharded comparison row of multi-GPU runs")
+    ap.add_argument("--term-row-deadline", type=float, default=120.0, help="seconds allowed for the term-sharded comparison row")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real run) | gloo (rehearsal: all ranks share GPU 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the baseline sample")
     return ap.parse_args()
@@ -152,6 +154,7 @@ def main():
         launches = st["probe_launches"]
         parallelism = "1 GPU"
         extra = {}
+        hung = False
     else:
         from apss.dist import ShardedJoin
         # distinct scored candidate pairs of the workload (a pair sharing terms in k shards is touched by k shards):
@@ -191,10 +194,13 @@ def main():
         # comparison row, measured in the same run: the term-sharded layout of BASELINE.json configs[3] (T = 2 term
         # ranges per candidate range, candidate all-gather + RCCL all-reduce of partial scores); not part of `value`
         term_row = None
+        hung = False
         if world % 2 == 0 and (a.term_shards or 1) == 1 and not a.no_term_row:
-            try:
-                del sj.engine
-                torch.cuda.empty_cache()
+            del sj.engine
+            torch.cuda.empty_cache()
+
+            def term_sharded_step():
+                torch.cuda.set_device(dev)
                 sj2 = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev,
                                   term_shards=2)
                 sj2.load(rp, idx, val)
@@ -205,10 +211,24 @@ def main():
                 sync()
                 t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=comm_dev)
                 dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-                term_row = {"grid": "2 term ranges x %d candidate ranges" % (world // 2), "ms_per_step": float(t2.item()) * 1e3,
-                            "result_pairs": int(n2), "exchange": sj2.last["exchange"]}
-            except Exception as e:  # the comparison row must never take the benchmark down
-                term_row = {"error": repr(e)[:200]}
+                return {"grid": "2 term ranges x %d candidate ranges" % (world // 2), "ms_per_step": float(t2.item()) * 1e3,
+                        "result_pairs": int(n2), "exchange": sj2.last["exchange"]}
+
+            # the comparison row must never take the benchmark down: it runs under a deadline on every rank; a rank
+            # that raises or stalls (its peers then wait in a collective) reports the fact and the main line still prints
+            box = {}
+
+            def guarded():
+                try:
+                    box["row"] = term_sharded_step()
+                except Exception as e:
+                    box["row"] = {"error": repr(e)[:200]}
+
+            th = threading.Thread(target=guarded, daemon=True)
+            th.start()
+            th.join(a.term_row_deadline)
+            hung = th.is_alive()
+            term_row = {"error": "no answer within %g s" % a.term_row_deadline} if hung else box.get("row")
         parallelism = ("%d candidate ranges, no data-path collective (term-sharded layouts: --term-shards)" % sj.D
                        if sj.T == 1 else "%d term-range shards x %d candidate ranges; per term group: candidate "
                        "all-gather + RCCL all-reduce of partial scores" % (sj.T, sj.D))
@@ -216,6 +236,8 @@ def main():
                  "backend": a.backend, "term_sharded_comparison": term_row}
 
     if rank != 0:
+        if world > 1 and hung:
+            os._exit(0)  # a stalled comparison step still holds a collective: do not wait for it
         if world > 1:
             dist.destroy_process_group()
         return
@@ -270,7 +292,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds)
     elif not a.no_cpu_baseline:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1 and hung:
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 
