@@ -468,6 +468,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.theta_fxi = (int32_t)std::max(-2147483647.0, std::min(2147483647.0, std::ceil(theta * scale_used)));
   const bool coarse_two = h->cx.cb <= 16384;  // small coarse tiles (tests): same shape, smaller lists
   const bool cx_big = h->cx.cb > 32768;  // experiment: one 1024-thread workgroup per CU over a 65536-row tile
+  // the sparse regime's wave holds few, short segments: a 3-step register window (24 chunks per wave) wastes fewer idle
+  // steps than the 5-step one as long as a wave's expected chunks stay well inside it (C5 shape: 458 vs 604 ms at N=2M)
+  const double cx_seg = (double)h->cx.cb * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;
+  const double cx_wave_chunks = ((double)q_nnz_end / (double)nq / 16.0) * std::max(1.0, cx_seg / 16.0 + 0.5);
+  const bool cx_big_u3 = cx_big && cx_wave_chunks <= 17.0 && !getenv("APSS_CX_BIG_U5");
   const bool cx8 = getenv("APSS_CX_CHUNK8") != nullptr;  // experiment: 8-posting chunks, 4 steps
   const int vrow_part = 512;
   // (the filter kernels keep their LDS in static arrays: no dynamic allocation)
@@ -547,14 +552,24 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     a.n_tiles = (int32_t)std::min<int64_t>(tiles_per_launch, total_tiles - t0);
     if (coarse_path) {
       if (a.vq_first && cx_big) {
-        auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, true>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+        if (cx_big_u3) {
+          auto kern = k_probe_coarse<1024, 3, 256, 1024, false, 16, true>;
+          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+        } else {
+          auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, true>;
+          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+        }
       } else if (a.vq_first) {
         auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, true>;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
       } else if (cx_big) {
-        auto kern = k_probe_coarse<1024, 5, 256, 1024, false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+        if (cx_big_u3) {
+          auto kern = k_probe_coarse<1024, 3, 256, 1024, false>;
+          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+        } else {
+          auto kern = k_probe_coarse<1024, 5, 256, 1024, false>;
+          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+        }
       } else if (getenv("APSS_CX_U3") && !h->sharded) {  // test hook: a 24-chunk window, most rounds overflow it
         auto kern = k_probe_coarse<512, 3, 128, 512, false>;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
