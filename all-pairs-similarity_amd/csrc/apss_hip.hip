@@ -466,7 +466,6 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.fx_scale = (float)scale_used;
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::max(1.0, std::ceil(theta * scale_used)));
   a.theta_fxi = (int32_t)std::max(-2147483647.0, std::min(2147483647.0, std::ceil(theta * scale_used)));
-  const bool coarse_two = h->cx.cb <= 16384;  // small coarse tiles (tests): same shape, smaller lists
   const bool cx_big = h->cx.cb > 32768;  // experiment: one 1024-thread workgroup per CU over a 65536-row tile
   // the sparse regime's wave holds few, short segments: a 3-step register window (24 chunks per wave) wastes fewer idle
   // steps than the 5-step one as long as a wave's expected chunks stay well inside it (C5 shape: 458 vs 604 ms at N=2M)
@@ -479,7 +478,6 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const size_t lds = coarse_path ? 0
                      : wave_path ? probe_wave_lds_bytes(h->ex.cb, wave_block, wave_u, wave_longcap, wave_survcap)
                                  : probe_lds_bytes(h->ex.cb, kProbeBlock, mode);
-  (void)coarse_two;
   auto launch_wave = [&](bool diag) -> int32_t {
     const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
 #define APSS_LAUNCH_WAVE1(B, UU, LC, SC, SH, DG)                                                                         \
