@@ -50,6 +50,7 @@ struct apss_handle {
   int64_t n_rows = 0, nnz = 0;
   DevBuf<int64_t> rowptr, ext;
   DevBuf<int32_t> idx;
+  DevBuf<uint32_t> erow;  // store row of every entry
   DevBuf<float> val, sub;  // sub: shard sub-norm per row (sharded only)
   // index (tile-major CSC) -- invertedIndex, IWA:25.  Two renderings of the same posting lists:
   //   ex: exact, 8-B postings, `cb` rows per tile      (k_probe_wave, k_probe, shard mode)
@@ -238,6 +239,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   APSS_TRY(ensure(h, o_ext, (size_t)(dst_row0 + kept_rows), (size_t)dst_row0));
   APSS_TRY(ensure(h, o_idx, (size_t)(dst_nnz0 + kept_nnz), (size_t)dst_nnz0));
   APSS_TRY(ensure(h, o_val, (size_t)(dst_nnz0 + kept_nnz), (size_t)dst_nnz0));
+  if (to_store) APSS_TRY(ensure(h, h->erow, (size_t)(dst_nnz0 + kept_nnz), (size_t)dst_nnz0));
   if (h->sharded) APSS_TRY(ensure(h, o_sub, (size_t)(dst_row0 + kept_rows), (size_t)dst_row0));
   if (dst_row0 == 0) HIPCHK(h, hipMemsetAsync(o_rowptr.p, 0, sizeof(int64_t), h->stream));
 
@@ -250,6 +252,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   w.o_val = o_val.p;
   w.o_ext = o_ext.p;
   w.o_sub = h->sharded ? o_sub.p : nullptr;
+  w.o_erow = to_store ? h->erow.p : nullptr;
   w.ext = d_ext;
   if (transform) {
     w.row_dst = h->s_rowdst.p;
@@ -282,7 +285,11 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   if (ix.h_base.empty()) ix.h_base.push_back(0);
   ix.h_base.resize((size_t)tile0 + 1);  // bases of the tiles that stay
   const int64_t r0 = tile0 * cb;
-  HIPCHK(h, hipMemsetAsync(ix.seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
+  // small dims: counters and cursors of a (tile, term range) live in one workgroup's LDS (no global atomics)
+  const int32_t n_ranges = (int32_t)ceil_div(h->cfg.dim, kBuildRange);
+  const bool lds_build = n_ranges <= kBuildMaxRanges && !getenv("APSS_BUILD_ATOMIC");
+  if (!lds_build)
+    HIPCHK(h, hipMemsetAsync(ix.seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
   BuildArgs b{};
   b.rowptr = h->rowptr.p;
   b.idx = h->idx.p;
@@ -295,13 +302,16 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.seg_stride = stride;
   b.coarse = ix.coarse ? 1 : 0;
   b.seg_align = ix.align;
+  b.erow = h->erow.p;
   b.coarse_shift = ix.coarse && ix.cb <= 32768 ? 1 : 0;  // must agree with k_probe_coarse's SLOT2 (the 512-thread kernels)
   const int threads = 256;
   const int64_t blocks = ceil_div((h->n_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
+  const dim3 lds_grid((unsigned)((n_tiles - tile0) * n_ranges));
+  if (lds_build) hipLaunchKernelGGL(k_tile_hist_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
+  else hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
   hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, ix.seg.p, stride, h->cfg.dim,
-                     tile0, ix.total.p, (uint32_t)ix.align);
+                     tile0, ix.total.p, (uint32_t)ix.align, lds_build ? 1u : 0u);
   HIPCHK(h, hipGetLastError());
   // padded posting counts -> tile bases (host prefix sum: a handful of values), then reserve the posting array
   std::vector<int64_t> tot((size_t)(n_tiles - tile0));
@@ -319,7 +329,8 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.tile_post_base = ix.base.p;
   b.post = ix.post.p;
   b.post_c = ix.post_c.p;
-  hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
+  if (lds_build) hipLaunchKernelGGL(k_tile_scatter_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
+  else hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
   if (h->sharded)
     hipLaunchKernelGGL(k_tile_min_sub, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream,
                        (const float *)h->sub.p, h->n_rows, (int32_t)cb, tmin.p, tile0);
@@ -820,6 +831,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   }
   if (cfg->capacity_nnz > 0) {
     if (ensure(h, h->idx, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
+        ensure(h, h->erow, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
         ensure(h, h->val, (size_t)cfg->capacity_nnz, 0, true) != APSS_OK ||
         (h->use_coarse ? ensure(h, h->cx.post_c, (size_t)cfg->capacity_nnz * 2 + 64, 0, true)
                        : ensure(h, h->ex.post, (size_t)cfg->capacity_nnz + (size_t)cfg->capacity_nnz / 2 + 64, 0, true)) != APSS_OK) {
@@ -836,7 +848,7 @@ void apss_destroy(apss_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-  release(h->rowptr); release(h->ext); release(h->idx); release(h->val); release(h->sub);
+  release(h->rowptr); release(h->ext); release(h->idx); release(h->erow); release(h->val); release(h->sub);
   for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); }
   release(h->tile_min); release(h->tile_min_c); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);

@@ -157,6 +157,7 @@ struct IngestWriteArgs {
   float *o_val;
   int64_t *o_ext;
   float *o_sub;  // sub-norm per destination row (may be null)
+  uint32_t *o_erow;  // destination row of every kept entry (store only; the LDS index build streams entries)
   const int64_t *ext;
 };
 
@@ -189,6 +190,7 @@ __global__ void k_ingest_write(IngestWriteArgs w) {
       const int64_t o = out + __popc(gm & ((1u << gl) - 1u));
       w.o_idx[o] = t;
       w.o_val[o] = v;
+      if (w.o_erow) w.o_erow[o] = (uint32_t)dr;
     }
     out += __popc(gm);
   }
@@ -258,6 +260,7 @@ struct BuildArgs {
   int32_t coarse;
   int32_t coarse_shift;           // 1: the slot field holds slot * 2, the byte offset of the 16-bit accumulator (tiles <= 32768 rows)
   int32_t seg_align;              // postings per aligned unit (kSegAlign / kSegAlignC)
+  const uint32_t *erow;           // store row of every entry (LDS build)
 };
 
 // one wave per row: coalesced reads of the row's entries
@@ -272,7 +275,7 @@ __global__ void k_tile_hist(BuildArgs a) {
 
 // one workgroup per tile: exclusive scan of the aligned lengths; tile_total[tile] = postings incl. padding
 __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0,
-                                                    int64_t *tile_total, uint32_t align) {
+                                                    int64_t *tile_total, uint32_t align, uint32_t keep_len) {
   __shared__ uint32_t part[1024];
   uint2 *sg = tile_seg + (tile0 + blockIdx.x) * seg_stride;
   const int tid = threadIdx.x;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
   uint32_t run = part[tid] - s;
   for (int32_t i = b; i < e; ++i) {
     const uint32_t len = sg[i].y;
-    sg[i] = make_uint2(run, 0u);
+    sg[i] = make_uint2(run, keep_len ? len : 0u);  // (the atomic scatter rebuilds .y as its cursor, the LDS scatter never touches it)
     run += (len + align - 1) / align * align;
   }
   if (tid == 1023) tile_total[tile0 + blockIdx.x] = part[1023];
@@ -318,6 +321,72 @@ __global__ void k_tile_scatter(BuildArgs a) {
       p.slot = local;
       p.w = a.val[k];
       a.post[pbase + pos] = p;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS index build, for dims of at most kBuildMaxRanges ranges of kBuildRange terms: one workgroup per (tile, term range)
+// streams the tile's entries and keeps the range's counters / cursors in LDS, so the 2 x 1e8 global atomics of
+// k_tile_hist / k_tile_scatter (2.7e10/s on this part, whatever their scope) become LDS atomics.  Each range re-reads
+// the tile's entries, which is why large dims (C5: 1M terms = 31 ranges) stay with the global-atomic kernels.
+constexpr int kBuildRange = 32768;    // 128 KB of LDS counters: one workgroup per CU
+constexpr int kBuildMaxRanges = 8;
+
+__global__ __launch_bounds__(1024) void k_tile_hist_lds(BuildArgs a, int64_t tile0, int32_t n_ranges) {
+  __shared__ uint32_t cnt[kBuildRange];
+  const int tid = threadIdx.x;
+  const int64_t tile = tile0 + blockIdx.x / n_ranges;
+  const int32_t lo = (int32_t)(blockIdx.x % n_ranges) * kBuildRange;
+  const uint32_t span = (uint32_t)(min(a.dim, lo + kBuildRange) - lo);
+  for (int i = tid; i < kBuildRange; i += 1024) cnt[i] = 0u;
+  __syncthreads();
+  const int64_t rA = tile * a.cb, rB = min(a.row1, rA + (int64_t)a.cb);
+  const int64_t eA = a.rowptr[rA], eB = a.rowptr[rB];
+  for (int64_t k = eA + tid; k < eB; k += 4096) {  // four loads in flight per thread
+    int32_t t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = k + 1024 * j < eB ? a.idx[k + 1024 * j] : -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((uint32_t)(t[j] - lo) < span) atomicAdd(&cnt[t[j] - lo], 1u);
+  }
+  __syncthreads();
+  uint2 *sg = a.tile_seg + tile * a.seg_stride + lo;
+  for (uint32_t i = tid; i < span; i += 1024) sg[i] = make_uint2(0u, cnt[i]);
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scatter_lds(BuildArgs a, int64_t tile0, int32_t n_ranges) {
+  __shared__ uint32_t cur[kBuildRange];
+  const int tid = threadIdx.x;
+  const int64_t tile = tile0 + blockIdx.x / n_ranges;
+  const int32_t lo = (int32_t)(blockIdx.x % n_ranges) * kBuildRange;
+  const uint32_t span = (uint32_t)(min(a.dim, lo + kBuildRange) - lo);
+  const uint2 *sg = a.tile_seg + tile * a.seg_stride + lo;
+  for (uint32_t i = tid; i < span; i += 1024) cur[i] = sg[i].x;  // cursor = segment start: the atomic returns the position
+  __syncthreads();
+  const int64_t pbase = a.tile_post_base[tile];
+  const int64_t rA = tile * a.cb, rB = min(a.row1, rA + (int64_t)a.cb);
+  const int64_t eA = a.rowptr[rA], eB = a.rowptr[rB];
+  for (int64_t k = eA + tid; k < eB; k += 4096) {
+    int32_t t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = k + 1024 * j < eB ? a.idx[k + 1024 * j] : -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if ((uint32_t)(t[j] - lo) < span) {
+        const int64_t e = k + 1024 * j;
+        const uint32_t pos = atomicAdd(&cur[t[j] - lo], 1u);
+        const uint32_t local = a.erow[e] - (uint32_t)rA;
+        if (a.coarse) {
+          a.post_c[pbase + pos] = pack_coarse(local << a.coarse_shift, a.val[e]);
+        } else {
+          Posting p;
+          p.slot = local;
+          p.w = a.val[e];
+          a.post[pbase + pos] = p;
+        }
+      }
     }
   }
 }

@@ -405,3 +405,19 @@ def test_candidate_pair_count_is_exact_when_the_window_overflows(apss_mod, monke
     assert st["candidate_pairs"] == truth
     assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
     assert st["filter_survivors"] >= st["result_pairs"] > 1000
+
+
+@pytest.mark.parametrize("path", ["two_pass", "exact_wave"])
+def test_global_atomic_index_build_matches_the_lds_build(apss_mod, monkeypatch, path):
+    """dims of more than 8 x 32768 terms build their index with global atomics (maildir: 2^20); the hook forces that
+    path on a small dim: same pairs, same counters as the LDS-cursor build the other tests use"""
+    from apss import _lib
+    z = np.load(os.path.join(GOLDEN, "mini_zipf_t05.npz"))
+    dim, theta = int(z["dim"]), float(z["theta"])
+    flags = {"two_pass": 0, "exact_wave": _lib.FLAG_EXACT_ACCUM}[path]
+    ref, st_ref = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=256, flags=flags)
+    monkeypatch.setenv("APSS_BUILD_ATOMIC", "1")
+    got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=256, flags=flags)
+    assert got.keys() == ref.keys() and st["candidate_pairs"] == st_ref["candidate_pairs"]
+    assert st["posting_visits"] == st_ref["posting_visits"] and st["nnz"] == st_ref["nnz"]
+    assert_same_pairs(got, to_map(z["out_q"], z["out_c"], z["out_sim"]), theta)
