@@ -68,14 +68,20 @@ class HipShardEngine:
             self.s_ids = self.d_ids[self.r0:self.r1].contiguous()
         torch.cuda.synchronize()
 
-    def candidates(self):
-        """phase 1: rebuild the shard's index and return its candidate pairs (query row, candidate row), global rows"""
+    def join(self):
+        """rebuild the shard's index and run its join; returns the number of pairs it reports (they stay on the device)"""
         self.ix.clear()
         if self.whole:
-            self.ix.insert_and_query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
+            n = self.ix.insert_and_query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
         else:
             self.ix.insert_dev(self.s_ids, self.s_rp, self.s_idx, self.s_val)
-            self.ix.query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
+            n = self.ix.query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
+        self.stats = self.ix.stats()
+        return n
+
+    def candidates(self):
+        """phase 1: rebuild the shard's index and return its candidate pairs (query row, candidate row), global rows"""
+        self.join()
         q, c, sc = self.ix.fetch()  # external ids == global row numbers
         self.stats = self.ix.stats()
         self.scores = sc  # final scores when the handle holds the whole term space (T == 1)
@@ -162,6 +168,22 @@ class ShardedJoin:
         return torch.cat([o[:s] for o, s in zip(out, sizes)]).to(self.device), sizes
 
     def step(self, return_pairs=False):
+        if self.T == 1 and not return_pairs and hasattr(self.engine, "join"):
+            # candidate ranges only: the handle's answer is final; count it without bringing the pairs to the host
+            n_mine = self.engine.join()
+            st = self.engine.stats
+            tot = torch.tensor([float(st.get("posting_visits", 0)), float(st.get("candidate_pairs", 0)), float(n_mine)],
+                               dtype=torch.float64, device=self.comm)
+            if self.world > 1:
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            self.last = {
+                "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0),
+                "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
+                "exchange": {"term_shards": 1, "candidate_ranges": self.D, "candidates_per_rank": [int(n_mine)],
+                             "union": int(n_mine), "all_gather_bytes_per_rank": 0, "all_reduce_bytes": 0,
+                             "term_ranges": self.ranges},
+            }
+            return int(tot[2].item())
         q, c = self.engine.candidates()
         if self.T == 1:
             # the handle holds the whole term space: its answer for this candidate range is already exact and pruned

@@ -287,7 +287,10 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   const int64_t r0 = tile0 * cb;
   // small dims: counters and cursors of a (tile, term range) live in one workgroup's LDS (no global atomics)
   const int32_t n_ranges = (int32_t)ceil_div(h->cfg.dim, kBuildRange);
-  const bool lds_build = n_ranges <= kBuildMaxRanges && !getenv("APSS_BUILD_ATOMIC");
+  // (one workgroup per (tile, range): with fewer than ~48 of them -- a small batch, a rebuilt tail tile, a 1/8 candidate
+  // range -- the row-parallel global-atomic kernels are faster; APSS_BUILD_LDS / APSS_BUILD_ATOMIC force either)
+  const bool lds_build = n_ranges <= kBuildMaxRanges && !getenv("APSS_BUILD_ATOMIC") &&
+                         ((n_tiles - tile0) * n_ranges >= 48 || getenv("APSS_BUILD_LDS"));
   if (!lds_build)
     HIPCHK(h, hipMemsetAsync(ix.seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
   BuildArgs b{};

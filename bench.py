@@ -114,16 +114,17 @@ def main():
         tr = term_ranges(np.bincount(idx, minlength=cfg["dim"]), T)[ti]
         eng = HipShardEngine(cfg["dim"], cfg["theta"], tr, dev, a.tile_rows)
         eng.load(rp, idx, val, None if D == 1 else (n * dj // D, n * (dj + 1) // D))
-        eng.candidates()
+        step = eng.join if T == 1 else (lambda: int(eng.candidates()[0].numel()))  # term shards hand their candidates on
+        step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            q, c = eng.candidates()
+            n_c = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
         print(json.dumps({"solo_shard": a.solo, "ms_per_step": dt * 1e3, "probe_kernel_ms": eng.stats["probe_ms"],
                           "build_ms": eng.stats["build_ms"], "posting_visits": eng.stats["posting_visits"],
-                          "candidates": int(q.numel())}))
+                          "candidates": int(n_c)}))
         return
     if world == 1:
         d_rp = torch.from_numpy(rp).to(dev)

@@ -415,7 +415,9 @@ def test_global_atomic_index_build_matches_the_lds_build(apss_mod, monkeypatch, 
     z = np.load(os.path.join(GOLDEN, "mini_zipf_t05.npz"))
     dim, theta = int(z["dim"]), float(z["theta"])
     flags = {"two_pass": 0, "exact_wave": _lib.FLAG_EXACT_ACCUM}[path]
+    monkeypatch.setenv("APSS_BUILD_LDS", "1")  # (small batches default to the atomic build)
     ref, st_ref = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=256, flags=flags)
+    monkeypatch.delenv("APSS_BUILD_LDS")
     monkeypatch.setenv("APSS_BUILD_ATOMIC", "1")
     got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=256, flags=flags)
     assert got.keys() == ref.keys() and st["candidate_pairs"] == st_ref["candidate_pairs"]
