@@ -582,6 +582,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
           auto kern = k_probe_coarse<1024, 5, 256, 1024, false>;
           hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
         }
+      } else if (getenv("APSS_CX_U4") && !h->sharded) {  // experiment hook: a 32-chunk window
+        auto kern = k_probe_coarse<512, 4, 128, 512, false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
       } else if (getenv("APSS_CX_U3") && !h->sharded) {  // test hook: a 24-chunk window, most rounds overflow it
         auto kern = k_probe_coarse<512, 3, 128, 512, false>;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
