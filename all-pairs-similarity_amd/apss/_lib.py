@@ -56,6 +56,12 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise RuntimeError("libapss_hip.so is not built (%s): run __graft_entry__.build() / make -C %s. "
                            "There is no CPU fallback." % (SO_PATH, CSRC))
+    # PyTorch-ROCm ships its own HIP runtime; if it is going to be used in this process (device-pointer entry points,
+    # apss.dist) it has to be loaded before ours pulls in the system's libamdhip64, or the second runtime finds no device
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     L = C.CDLL(SO_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
     pi64 = C.POINTER(C.c_int64)
