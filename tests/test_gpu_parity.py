@@ -423,3 +423,46 @@ def test_global_atomic_index_build_matches_the_lds_build(apss_mod, monkeypatch, 
     assert got.keys() == ref.keys() and st["candidate_pairs"] == st_ref["candidate_pairs"]
     assert st["posting_visits"] == st_ref["posting_visits"] and st["nnz"] == st_ref["nnz"]
     assert_same_pairs(got, to_map(z["out_q"], z["out_c"], z["out_sim"]), theta)
+
+
+def test_handles_are_independent_across_threads(apss_mod, oracle):
+    """the actor model of the reference (akka.conf:20-31): different workers run concurrently on a dispatcher's threads and
+    a worker's thread may change between messages -- four handles driven from four threads at once (ctypes drops the GIL
+    inside the library), then one handle passed from thread to thread"""
+    import threading
+    jobs = []
+    for s in range(4):
+        n, dim, nnz, theta = 3000 + 500 * s, 1500 + 100 * s, 20, 0.5
+        rp, idx, val = synth.make_vectors(n, dim, nnz, 0.5 * (s % 2), seed=200 + s, dup_frac=0.1)
+        jobs.append((dim, theta, rp, idx, val, to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))))
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            dim, theta, rp, idx, val, _ = jobs[i]
+            for _ in range(3):  # several joins per thread so that the calls really overlap
+                got[i], _st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=512)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert_same_pairs(got[i], jobs[i][5], jobs[i][1])
+    # one handle, a different thread for every message
+    dim, theta, rp, idx, val, want = jobs[0]
+    n = len(rp) - 1
+    stream = {}
+    with apss_mod.ApssIndex(dim, theta, tile_rows=256) as ix:
+        def msg(b0, b1):
+            sl = slice(rp[b0], rp[b1])
+            stream.update(to_map(*ix.insert_and_query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])))
+        for b0 in range(0, n, 1000):
+            t = threading.Thread(target=msg, args=(b0, min(n, b0 + 1000)))
+            t.start()
+            t.join()
+    assert_same_pairs(stream, {k: v for k, v in want.items() if k[0] >= (k[1] // 1000) * 1000}, theta)
