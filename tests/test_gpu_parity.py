@@ -387,6 +387,10 @@ def test_stratified_fullsize_property_reduced():
     out = mod.run(300_000, 100_000, 50, 0.85, seed=7)
     assert out["missing"] == 0 and out["unexpected"] == 0 and out["planted_pairs_required"] > 10_000
     assert out["tiles"] >= 5
+    # BASELINE.json configs[2] at full size (the shape bench.py measures), stratified: every planted pair, nothing else
+    out = mod.run(1_000_000, 100_000, 100, 0.8, seed=20242)
+    assert out["missing"] == 0 and out["unexpected"] == 0 and out["planted_pairs_required"] > 50_000
+    assert out["tiles"] == 31 and out["probe_launches"] == 1 and out["max_abs_score_error"] <= 1e-5
 
 
 @pytest.mark.parametrize("hook", [None, "APSS_CX_CHUNK8", "APSS_CX_U3"])
