@@ -1396,26 +1396,25 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     }
   };
 
-  RowExt R1 = load_R(v0 + 1), R2 = load_R(v0 + 2), R3 = load_R(v0 + 3), R4 = load_R(v0 + 4);
-  TermW I3, I4;
-  Seg P2, P3;
-  WaveWork wfa, wfb, wfc;
+  RowExt R1 = load_R(v0 + 1), R2 = load_R(v0 + 2), R3 = load_R(v0 + 3);
+  TermW I2, I3;
+  Seg P1, P2;
+  WaveWork wfa, wfb;
   {
     const RowExt R0 = load_R(v0);
-    const TermW I0 = load_I(R0), I1 = load_I(R1), I2 = load_I(R2);
-    I3 = load_I(R3);
-    const Seg P0 = load_P(I0), P1 = load_P(I1);
-    P2 = load_P(I2);
+    const TermW I0 = load_I(R0), I1 = load_I(R1);
+    I2 = load_I(R2);
+    const Seg P0 = load_P(I0);
+    P1 = load_P(I1);
     __syncthreads();
     flatten(wfa, P0, R0, 0);
-    flatten(wfb, P1, R1, 1);
   }
   __syncthreads();
   n_long_next = ctr[0];
 
   bool multi = false;    // the current query has earlier parts whose slots are no longer in registers
   bool rescan = false;   // an earlier part overflowed the survivor list: scan the accumulators at the last part
-  auto round = [&](WaveWork &w0, WaveWork &w2, const int v, const int l3, const RowExt cur) {
+  auto round = [&](WaveWork &w0, WaveWork &w2, const int v, const int l3, const RowExt cur) {  // (l3: ring slot, 0/1)
     const int par = (v - v0) & 1;
     const int q = cur.q;
     // coarse threshold: products are rounded UP (add16), so a coarse sum is never below S * sum(q_i * fp16(c_i)); the 2
@@ -1426,10 +1425,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     const int thr_c = (SHARD ? (int)floorf(a.cx_theta * qs * tile_scale) : (int)a.cx_theta) - slack;
     const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
 
-    const RowExt R5 = load_R(v + 5);
-    I4 = load_I(R4);
-    P3 = load_P(I3);
-    flatten(w2, P2, R2, l3 == 0 ? 2 : l3 - 1);
+    const RowExt R4 = load_R(v + 4);
+    I3 = load_I(R3);
+    P2 = load_P(I2);
+    flatten(w2, P1, R1, l3 ^ 1);
 
     auto crossed = [&](const uint32_t slot, const uint32_t p, const uint32_t old16) {
       if (thr1 - old16 < p) {
@@ -1547,7 +1546,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     __syncthreads();
 
     const uint2 fl = *reinterpret_cast<const uint2 *>(&ctr[4 + 2 * par]);
-    n_long_next = ctr[l3 == 2 ? 0 : l3 + 1];
+    n_long_next = ctr[l3 ^ 1];
     const uint32_t n_surv = fl.y;
     // a part that is not the query's last only adds; reporting and clearing wait for the last part
     // a multi-part query reports once, at its last part, by scanning the accumulators (no duplicates across parts)
@@ -1617,26 +1616,21 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     }
     __syncthreads();
 
-    P2 = P3;
-    I3 = I4;
+    P1 = P2;
+    I2 = I3;
     R1 = R2;
     R2 = R3;
     R3 = R4;
-    R4 = R5;
   };
   // the extent of round v is R0 of that round; track it alongside (R1 is round v+1 at the top of round v)
   RowExt cur = load_R(v0);
-  for (int v = v0; v < v1; v += 3) {
+  for (int v = v0; v < v1; v += 2) {
     RowExt nx = R1;
-    round(wfa, wfc, v, 0, cur);
+    round(wfa, wfb, v, 0, cur);
     cur = nx;
     if (v + 1 >= v1) break;
     nx = R1;
     round(wfb, wfa, v + 1, 1, cur);
-    cur = nx;
-    if (v + 2 >= v1) break;
-    nx = R1;
-    round(wfc, wfb, v + 2, 2, cur);
     cur = nx;
   }
   __syncthreads();
