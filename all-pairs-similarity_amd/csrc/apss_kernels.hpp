@@ -1426,9 +1426,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
 
     const RowExt R4 = load_R(v + 4);
-    I3 = load_I(R3);
-    P2 = load_P(I2);
-    flatten(w2, P1, R1, l3 ^ 1);
 
     auto crossed = [&](const uint32_t slot, const uint32_t p, const uint32_t old16) {
       if (thr1 - old16 < p) {
@@ -1460,11 +1457,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       crossed(slot_of(pcw), p, old16);
     };
     // the register window, BATCH steps (2 x BATCH atomics) at a time: enough LDS atomics in flight to cover their
-    // latency, few enough live registers to keep two workgroups on the CU
+    // latency, few enough live registers to keep two workgroups on the CU.  The staging of round v + 1 (its own LDS
+    // round trip and its posting loads) runs between the first batch's adds and their tests.
     constexpr int BATCH = 3;
-#pragma unroll
-    for (int u0 = 0; u0 < U; u0 += BATCH) {
-      uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
+    auto issue_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
       // an idle lane (zero word) skips only the atomic; its "old value" thr1 + 1 is never a first touch (not 0) and
       // never a crossing (thr1 - old wraps to 2^32 - 1), whatever its p
 #pragma unroll
@@ -1478,6 +1474,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
           if (w0.pc[u].y) o1[j] = add16(w0.pc[u].y, p1[j]);
         }
       }
+    };
+    auto check_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
       bool any_cross = false;
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
@@ -1499,6 +1497,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
           }
         }
       }
+    };
+    {
+      uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
+      issue_batch(0, p0, p1, o0, o1);
+      I3 = load_I(R3);
+      P2 = load_P(I2);
+      flatten(w2, P1, R1, l3 ^ 1);
+      check_batch(0, p0, p1, o0, o1);
+    }
+#pragma unroll
+    for (int u0 = BATCH; u0 < U; u0 += BATCH) {
+      uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
+      issue_batch(u0, p0, p1, o0, o1);
+      check_batch(u0, p0, p1, o0, o1);
     }
     if (w0.totch > WIN) {
       if (ln == 0) ctr[4 + 2 * par] = 1;
