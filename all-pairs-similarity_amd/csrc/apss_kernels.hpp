@@ -1382,6 +1382,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     for (uint32_t k = 0; k < kPuts; ++k) put(k);
     if (__any(nch > kPuts))
       for (uint32_t k = kPuts; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
+  };
+  // second half of the staging: every LPC lanes take one chunk of the strip and start its posting load
+  auto flatten_loads = [&](WaveWork &f) {
     uint2 it[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) it[u] = wl[u * GPW + ln / LPC];
@@ -1408,6 +1411,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     P1 = load_P(I1);
     __syncthreads();
     flatten(wfa, P0, R0, 0);
+    flatten_loads(wfa);
   }
   __syncthreads();
   n_long_next = ctr[0];
@@ -1506,10 +1510,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       flatten(w2, P1, R1, l3 ^ 1);
       check_batch(0, p0, p1, o0, o1);
     }
+    if (U <= BATCH) flatten_loads(w2);
 #pragma unroll
     for (int u0 = BATCH; u0 < U; u0 += BATCH) {
       uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
       issue_batch(u0, p0, p1, o0, o1);
+      if (u0 == BATCH) flatten_loads(w2);  // the strip round trip and the loads' issue overlap the second batch's adds
       check_batch(u0, p0, p1, o0, o1);
     }
     if (w0.totch > WIN) {
