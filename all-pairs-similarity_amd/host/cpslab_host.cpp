@@ -2,6 +2,8 @@
 #include "cpslab_host.hpp"
 
 #include <fstream>
+#include <iterator>
+#include <map>
 
 #include <algorithm>
 #include <chrono>
@@ -109,6 +111,81 @@ std::vector<std::pair<std::string, SparkSparseVector>> CCWEBVideoLoadGenerator::
   }
   return out;
 }
+
+namespace etl {
+int32_t javaStringHashCode(const std::string &s) {
+  uint32_t h = 0;
+  for (unsigned char ch : s) h = 31u * h + ch;
+  return (int32_t)h;
+}
+
+int32_t nonNegativeMod(int32_t x, int32_t mod) {
+  const int32_t r = x % mod;  // truncated, like the JVM's %
+  return r < 0 ? r + mod : r;
+}
+
+std::vector<std::string> documentTokens(const std::string &path) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw std::runtime_error("cannot open " + path);
+  std::string raw((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  // BufferedReader.readLine: "\n", "\r" and "\r\n" end a line; a final terminator does not start another line
+  std::string s;
+  size_t i = 0;
+  while (i < raw.size()) {
+    size_t j = i;
+    while (j < raw.size() && raw[j] != '\n' && raw[j] != '\r') ++j;
+    s.append(raw, i, j - i);
+    s.push_back(' ');
+    if (j < raw.size() && raw[j] == '\r' && j + 1 < raw.size() && raw[j + 1] == '\n') ++j;
+    i = j + 1;
+  }
+  s += "null ";
+  std::vector<std::string> toks;
+  size_t b = 0;
+  for (;;) {
+    const size_t e = s.find(' ', b);
+    toks.push_back(s.substr(b, e == std::string::npos ? e : e - b));
+    if (e == std::string::npos) break;
+    b = e + 1;
+  }
+  while (!toks.empty() && toks.back().empty()) toks.pop_back();  // String.split drops trailing empty strings
+  return toks;
+}
+
+SparseVector hashingTF(const std::vector<std::string> &tokens, int32_t numFeatures) {
+  std::map<int32_t, double> tf;
+  for (const auto &t : tokens) tf[nonNegativeMod(javaStringHashCode(t), numFeatures)] += 1.0;
+  std::vector<int32_t> idx;
+  std::vector<double> val;
+  for (const auto &kv : tf) {
+    idx.push_back(kv.first);
+    val.push_back(kv.second);
+  }
+  return SparseVector(numFeatures, std::move(idx), std::move(val));
+}
+
+std::vector<SparseVector> tfidf(const std::vector<SparseVector> &tf, bool normalize) {
+  std::map<int32_t, int64_t> df;
+  for (const auto &v : tf)
+    for (int32_t i : v.indices) ++df[i];
+  const double m = (double)tf.size();
+  std::vector<SparseVector> out;
+  for (const auto &v : tf) {
+    std::vector<double> w(v.values.size());
+    double ss = 0;
+    for (size_t k = 0; k < w.size(); ++k) {
+      w[k] = v.values[k] * std::log((m + 1.0) / ((double)df[v.indices[k]] + 1.0));
+      ss += w[k] * w[k];
+    }
+    if (normalize && ss > 0) {
+      const double nrm = std::sqrt(ss);
+      for (double &x : w) x /= nrm;
+    }
+    out.emplace_back(v.size, v.indices, std::move(w));
+  }
+  return out;
+}
+}  // namespace etl
 
 std::string SimilarityOutput::toString() const {  // Message.scala:23-34
   std::ostringstream o;

@@ -50,6 +50,20 @@ class CCWEBVideoLoadGenerator {
   std::string path_;
 };
 
+// ---- TF-IDF ingest of a text corpus (BASELINE config 1): etl/src/main/scala/cpslab/etl/PreprocessWithTFIDF.scala:21-52 with
+// Spark 1.2.0 mllib's HashingTF / IDF formulas (formula-level restatement: the Spark sources are not in the reference tree)
+namespace etl {
+int32_t javaStringHashCode(const std::string &s);  // java.lang.String.hashCode over ISO-8859-1 chars (one per byte)
+int32_t nonNegativeMod(int32_t x, int32_t mod);    // org.apache.spark.util.Utils.nonNegativeMod
+// PreprocessWithTFIDF.scala:33-41: every line + " ", then the literal "null " of the read loop, split on " "
+std::vector<std::string> documentTokens(const std::string &path);
+// mllib.feature.HashingTF(numFeatures).transform: index = nonNegativeMod(term.hashCode, numFeatures), value = count
+SparseVector hashingTF(const std::vector<std::string> &tokens, int32_t numFeatures = 1 << 20);
+// mllib.feature.IDF().fit(tf).transform(tf): idf_t = ln((m + 1) / (df_t + 1)); optional L2 normalisation
+// (benchmark/LoadGenerator.scala:34-37: the reference's client normalises, its ETL does not)
+std::vector<SparseVector> tfidf(const std::vector<SparseVector> &tf, bool normalize);
+}  // namespace etl
+
 struct VectorIOMsg { std::vector<std::pair<std::string, SparkSparseVector>> vectors; };  // Message.scala:13
 struct IndexData { std::vector<std::pair<std::string, SparseVector>> vectors; };         // Message.scala:18 (wrappers' payload)
 struct Test { std::string content; };                                                    // Message.scala:37

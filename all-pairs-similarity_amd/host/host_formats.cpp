@@ -2,9 +2,11 @@
 //   host_formats ccweb < lines      one "id<TAB>(size,[i,...],[v,...])" per line, "ERROR" where the reference throws
 //   host_formats vector < lines     SparseVector.fromString / toString round trip
 //   host_formats ccweb-file PATH    CCWEBVideoLoadGenerator(path).generateVectors
+//   host_formats tfidf NUM_FEATURES FILE...   the ETL's HashingTF + IDF (+ L2 normalisation), one vector per file
 #include <cstdio>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "cpslab_host.hpp"
 
@@ -18,6 +20,17 @@ int main(int argc, char **argv) {
         std::printf("%s\t%s\n", kv.first.c_str(), kv.second.toString().c_str());
     } catch (const std::exception &) {
       std::printf("ERROR\n");
+    }
+    return 0;
+  }
+  if (mode == "tfidf" && argc > 2) {  // tfidf NUM_FEATURES FILE...  (files in the order given = document order)
+    try {
+      const int nf = std::stoi(argv[2]);
+      std::vector<SparseVector> tf;
+      for (int i = 3; i < argc; ++i) tf.push_back(etl::hashingTF(etl::documentTokens(argv[i]), nf));
+      for (const auto &v : etl::tfidf(tf, true)) std::printf("%s\n", v.toString().c_str());
+    } catch (const std::exception &e) {
+      std::printf("ERROR %s\n", e.what());
     }
     return 0;
   }

@@ -263,6 +263,79 @@ def ccweb_line_parser(line):
     return f[0], size, nz.astype(np.int32), dense[nz]
 
 
+# ---- TF-IDF ingest of a text corpus (BASELINE config 1), restated from the reference's ETL
+# etl/src/main/scala/cpslab/etl/PreprocessWithTFIDF.scala:21-52 with Spark 1.2.0 mllib's HashingTF / IDF formulas (the
+# Spark sources are not in the reference tree: formula-level restatement)
+def java_string_hash(s):
+    """java.lang.String.hashCode over the string's chars (here: ISO-8859-1, one char per byte), int32 wrap-around"""
+    h = 0
+    for ch in s:
+        h = (31 * h + ord(ch)) & 0xFFFFFFFF
+    return h - (1 << 32) if h & 0x80000000 else h
+
+
+def non_negative_mod(x, mod):
+    """org.apache.spark.util.Utils.nonNegativeMod: the JVM's truncated remainder, shifted into [0, mod)"""
+    r = int(np.fmod(x, mod))
+    return r + mod if r < 0 else r
+
+
+def document_tokens(path):
+    """PreprocessWithTFIDF.scala:33-41: a file becomes ONE string -- every line + " ", then the literal "null " that the
+    read loop appends -- split on " " (java.lang.String.split: trailing empty strings dropped, inner ones kept)"""
+    raw = open(path, "rb").read().decode("latin-1")
+    lines = raw.replace("\r\n", "\n").replace("\r", "\n").split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()  # BufferedReader.readLine: a final line terminator does not start another line
+    s = "".join(ln + " " for ln in lines) + "null "
+    toks = s.split(" ")
+    while toks and toks[-1] == "":
+        toks.pop()
+    return toks
+
+
+def hashing_tf(tokens, num_features=1 << 20, cache=None):
+    """mllib.feature.HashingTF.transform: index = nonNegativeMod(term.hashCode, numFeatures), value = term count"""
+    tf = {}
+    for t in tokens:
+        i = cache.get(t) if cache is not None else None
+        if i is None:
+            i = non_negative_mod(java_string_hash(t), num_features)
+            if cache is not None:
+                cache[t] = i
+        tf[i] = tf.get(i, 0.0) + 1.0
+    return tf
+
+
+def idf_weights(tfs):
+    """mllib.feature.IDF (minDocFreq = 0): idf_t = ln((m + 1) / (df_t + 1)) over all m documents"""
+    df = {}
+    for tf in tfs:
+        for i in tf:
+            df[i] = df.get(i, 0) + 1
+    m = len(tfs)
+    return {i: float(np.log((m + 1.0) / (c + 1.0))) for i, c in df.items()}
+
+
+def tfidf_corpus(paths, num_features=1 << 20, normalize=True):
+    """the ETL over a list of files: CSR (rowptr, indices, values) of tf * idf, L2-normalised when `normalize` (the
+    reference's client does that, benchmark/LoadGenerator.scala:34-37; its ETL does not)"""
+    cache = {}
+    tfs = [hashing_tf(document_tokens(p), num_features, cache) for p in paths]
+    idf = idf_weights(tfs)
+    rowptr, idx, val = [0], [], []
+    for tf in tfs:
+        ks = sorted(tf)
+        v = np.array([tf[k] * idf[k] for k in ks], np.float64)
+        if normalize:
+            nrm = np.sqrt((v * v).sum())
+            v = v / nrm if nrm > 0 else v
+        idx += ks
+        val += list(v)
+        rowptr.append(len(idx))
+    return np.array(rowptr, np.int64), np.array(idx, np.int32), np.array(val, np.float64)
+
+
 def _java_int(s):
     if not s or not (s.lstrip("+-").isdigit() and s.isascii()) or s in "+-":
         raise ValueError("not an Int: %r" % s)

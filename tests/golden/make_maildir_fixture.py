@@ -24,53 +24,16 @@ THETA = 0.7
 STRIDE = 12
 
 
-def java_hash(s):
-    h = 0
-    for ch in s:
-        h = (31 * h + ord(ch)) & 0xFFFFFFFF
-    return h - (1 << 32) if h & 0x80000000 else h
-
-
-def non_negative_mod(x, mod):
-    r = int(np.fmod(x, mod))  # truncated remainder, like the JVM's %
-    return r + mod if r < 0 else r
-
-
-def doc_tokens(path):
-    raw = open(path, "rb").read().decode("latin-1")
-    lines = raw.replace("\r\n", "\n").replace("\r", "\n").split("\n")
-    if lines and lines[-1] == "":
-        lines.pop()  # BufferedReader.readLine: a final line terminator does not start another line
-    s = "".join(l + " " for l in lines) + "null "
-    toks = s.split(" ")
-    while toks and toks[-1] == "":
-        toks.pop()
-    return toks
-
-
 paths = sorted(os.path.join(d, f) for d, _, fs in os.walk(CORPUS) for f in fs)
 m = len(paths)
-cache, rows = {}, []
-df = {}
-for p in paths:
-    tf = {}
-    for t in doc_tokens(p):
-        i = cache.get(t)
-        if i is None:
-            i = cache[t] = non_negative_mod(java_hash(t), DIM)
-        tf[i] = tf.get(i, 0.0) + 1.0
-    rows.append(tf)
-    for i in tf:
-        df[i] = df.get(i, 0) + 1
-idf = {i: np.log((m + 1.0) / (c + 1.0)) for i, c in df.items()}
+# IDF over ALL m documents, then every STRIDE-th document goes into the fixture
+rp_all, idx_all, val_all = oracle.tfidf_corpus(paths, DIM, normalize=True)
 sel = list(range(0, m, STRIDE))
 rowptr, idx, val = [0], [], []
 for r in sel:
-    ks = sorted(rows[r])
-    v = np.array([rows[r][k] * idf[k] for k in ks])
-    nrm = np.sqrt((v * v).sum())
-    idx += ks
-    val += list(v / nrm if nrm > 0 else v)
+    sl = slice(rp_all[r], rp_all[r + 1])
+    idx += list(idx_all[sl])
+    val += list(val_all[sl])
     rowptr.append(len(idx))
 rowptr, idx = np.array(rowptr, np.int64), np.array(idx, np.int32)
 val = np.array(val, np.float64).astype(np.float32).astype(np.float64)  # stored at fp32 precision (smaller file)

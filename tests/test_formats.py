@@ -100,3 +100,37 @@ def test_sparse_vector_text_round_trip(host_formats, oracle):
             continue
         s2, i2, v2 = oracle.parse_sparse_vector(g)
         assert (s2, list(i2), list(v2)) == (size, list(idx), list(val))
+
+
+def test_tfidf_ingest_matches_the_etl_restatement(host_formats, oracle, tmp_path):
+    """etl/src/main/scala/cpslab/etl/PreprocessWithTFIDF.scala:21-52 (HashingTF + IDF, then the client's L2 normalisation)
+    in the C++ host mirror against the oracle's restatement, on a small corpus with the awkward cases: CRLF and bare CR
+    line ends, consecutive blanks (empty tokens), an empty file, non-ASCII bytes, a file without a final newline"""
+    rng = np.random.default_rng(5)
+    words = ["mail", "spark", "akka", "index", "vector", "the", "a", "GPU", "na\xefve", "caf\xe9", "x" * 40, "Re:", "42"]
+    docs = []
+    for i in range(25):
+        lines = [" ".join(rng.choice(words, size=int(rng.integers(0, 12)))) for _ in range(int(rng.integers(1, 8)))]
+        docs.append(("\r\n" if i % 3 == 0 else "\n").join(lines) + ("" if i % 4 == 0 else "\n"))
+    docs += ["", "one  two   three\n", "tail\rwith\rcarriage returns", "null\n"]
+    paths = []
+    for i, d in enumerate(docs):
+        p = tmp_path / ("doc%02d.txt" % i)
+        p.write_bytes(d.encode("latin-1"))
+        paths.append(str(p))
+    for nf in (1 << 20, 64):  # the ETL's 2^20 buckets, and a tiny space where hash collisions add up
+        rp, idx, val = oracle.tfidf_corpus(paths, nf, normalize=True)
+        out = subprocess.run([os.path.join(HOST, "host_formats"), "tfidf", str(nf)] + paths, capture_output=True, text=True)
+        got = out.stdout.splitlines()
+        assert len(got) == len(paths), out.stdout[:300] + out.stderr[:300]
+        for r, g in enumerate(got):
+            want_i, want_v = idx[rp[r]:rp[r + 1]], val[rp[r]:rp[r + 1]]
+            if len(want_i) == 0:
+                assert g == "(%d,[],[])" % nf
+                continue
+            size, gi, gv = oracle.parse_sparse_vector(g)
+            assert size == nf and list(gi) == list(want_i)
+            assert np.allclose(gv, want_v, rtol=1e-13, atol=0)
+    # the known hash values: "" -> 0, "a" -> 97, "null" -> 3392903 (java.lang.String.hashCode)
+    assert oracle.java_string_hash("") == 0 and oracle.java_string_hash("a") == 97 and oracle.java_string_hash("null") == 3392903
+    assert oracle.java_string_hash("polygenelubricants") == -2147483648 and oracle.non_negative_mod(-2147483648, 1 << 20) == 0
