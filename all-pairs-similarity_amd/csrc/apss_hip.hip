@@ -421,11 +421,18 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
 
   // ---- path 1: two-pass join (coarse filter + exact rescoring) ----
   // accumulator units per 1.0: a 16-bit sum holds S * |q||c| (fp16 weights: + 2^-11) plus one unit per shared term
-  const double cx_room = 65535.0 - (double)std::min<int64_t>(q_max_nnz, h->store_max_nnz);
-  const double cx_scale = bound * 1.0005 * 32768.0 < cx_room ? 32768.0 : (bound * 1.0005 * 16384.0 < cx_room ? 16384.0 : 0.0);
+  // S = the largest power of two that fits (2^15 for unit-norm input); un-normalised input gets a smaller one as long as
+  // the threshold in units stays well above the round-up bias (one unit per shared term), else the filter passes too much
+  const double cx_shared = (double)std::min<int64_t>(q_max_nnz, h->store_max_nnz);
+  const double cx_room = 65535.0 - cx_shared;
+  double cx_scale = 0.0;
+  for (int k = 15; k >= 4 && cx_scale == 0.0; --k)
+    if (bound * 1.0005 * std::ldexp(1.0, k) < cx_room) cx_scale = std::ldexp(1.0, k);
   const double cx_theta = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
+  const bool cx_selective = cx_scale >= 16384.0 || cx_theta >= 4.0 * cx_shared;
+  const bool cx_fp16_ok = std::sqrt((double)h->store_max_norm2) < 60000.0;  // a weight never exceeds its row's norm
   // (shard mode scales the threshold down per query and tile: the kernel clamps it at 1, which only admits more)
-  const bool coarse_path = h->use_coarse && mode == 0 && bound < 3.9 && !forced_general && nq < (1LL << 30) &&
+  const bool coarse_path = h->use_coarse && mode == 0 && cx_selective && cx_fp16_ok && !forced_general && nq < (1LL << 30) &&
                            !(h->sharded && h->cx.cb > 32768) &&
                            (q_max_nnz <= 512 || !h->sharded) &&
                            !getenv("APSS_EXACT_ACCUM") && cx_scale > 0 && cx_theta < 65000.0 && (h->sharded || cx_theta - 2 >= 1.0) &&

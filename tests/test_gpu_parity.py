@@ -259,16 +259,37 @@ def test_c3_shape_properties(apss_mod):
     assert st2["candidate_pairs"] == st["candidate_pairs"] and st["filter_survivors"] >= len(got)
 
 
-def test_unbounded_norms_use_the_float_path(apss_mod, oracle):
-    """row norms too large for the fixed-point accumulators (|q||c| >= 15.6): the fp32-atomic kernels must take over"""
+def test_unnormalised_input_keeps_the_two_pass_join(apss_mod, oracle):
+    """row norms of 10 (scores up to 100): the filter runs at 2^9 units per 1.0 instead of 2^15 (its 16-bit sums still
+    hold S |q||c| plus one unit per shared term), the exact pass is fp32 as ever; with exact accumulators only
+    (APSS_FLAG_EXACT_ACCUM) such norms are beyond the fixed-point kernels and the fp32-atomic kernel takes over"""
+    from apss import _lib
     n, dim, nnz = 1500, 300, 12
     rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=41, dup_frac=0.1)
-    big = val * 10.0  # norms 10 -> scores up to 100
+    big = val * 10.0
     theta = 45.0
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, big))
     assert len(want) > 100
-    got, _ = _gpu_join(apss_mod, dim, theta, rp, idx, big, tile_rows=512)
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, big, tile_rows=512)
+    assert st["filter_survivors"] >= len(want)
     assert_same_pairs(got, want, theta, band=1e-3, tol=1e-3)  # fp32 sums of values around 100
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, big, tile_rows=512, flags=_lib.FLAG_EXACT_ACCUM)
+    assert st["filter_survivors"] == 0
+    assert_same_pairs(got, want, theta, band=1e-3, tol=1e-3)
+
+
+def test_weights_beyond_fp16_use_the_float_path(apss_mod, oracle):
+    """row norms of 1e5: the coarse postings (fp16 weights) cannot hold them, the fp32-atomic kernel runs the join"""
+    n, dim, nnz = 1200, 300, 12
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=43, dup_frac=0.1)
+    huge = val * 1.0e5
+    theta = 4.5e9
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, huge))
+    assert len(want) > 100
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, huge, tile_rows=512)
+    assert st["filter_survivors"] == 0 and set(got) == set(want)
+    for k, v in got.items():
+        assert abs(v - want[k]) <= 1e-5 * abs(want[k])  # relative: scores of 1e10 in fp32
 
 
 def test_medium_norms_use_the_coarser_fixed_point_scale(apss_mod, oracle):
@@ -278,8 +299,13 @@ def test_medium_norms_use_the_coarser_fixed_point_scale(apss_mod, oracle):
     theta = 4.5
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, v3))
     assert len(want) > 100
-    got, _ = _gpu_join(apss_mod, dim, theta, rp, idx, v3, tile_rows=512)
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, v3, tile_rows=512)
+    assert st["filter_survivors"] >= len(want)  # two-pass at 2^12 units per 1.0
     assert_same_pairs(got, want, theta, band=1e-4, tol=1e-4)  # inputs are fp32 on the device: 6e-8 * 9 * terms
+    from apss import _lib
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, v3, tile_rows=512, flags=_lib.FLAG_EXACT_ACCUM)
+    assert st["filter_survivors"] == 0  # the single-pass kernel at its coarser scale, 2^28
+    assert_same_pairs(got, want, theta, band=1e-4, tol=1e-4)
 
 
 def test_maildir_small_plumbing(apss_mod):
