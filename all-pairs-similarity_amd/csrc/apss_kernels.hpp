@@ -1243,7 +1243,7 @@ __global__ void k_vrow_fill(const int64_t *rowptr, int64_t n, int part, const in
 // most one unit per shared term; the host picks S so that S*|q||c| + min(nnz_q, nnz_c) stays below 2^16 (no carry).
 // __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
 // sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.
-template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false>
+template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false, bool SIGNED = false>
 __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   constexpr bool SLOT2 = BLOCK <= 512;    // tiles of <= 32768 rows: the posting's slot field is slot * 2 (see pack_coarse)
@@ -1441,8 +1441,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     // (the half is extracted later, so that the round's atomics are all in flight before the first wait)
     auto slot_of = [&](const uint32_t pcw) { return SLOT2 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu; };
     // the product of one posting, rounded up: floor(x) + 1 is never below x and >= 1, so that a touch always shows
+    // SIGNED (weights of either sign, theta > 0): only the positive products count and a negative one adds a single
+    // unit, so a sum is an upper bound of S * score that still grows with every touch -- sound for a filter (a pair
+    // with score >= theta has at least that much positive mass); the exact pass applies the signs
     auto prod = [&](const uint32_t pcw, const float wqs) {
-      return (uint32_t)__builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(pcw >> 16))), 1.0f);
+      const float x = __builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(pcw >> 16))), 1.0f);
+      return SIGNED ? (uint32_t)max((int)x, 1) : (uint32_t)x;
     };
     // ds_add_rtn_u32 on the word that holds the candidate's half; halves cannot carry (bounded scores)
     auto add16 = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {

@@ -47,7 +47,7 @@ extern "C" {
 #define APSS_FLAG_ADMISSION 2u   /* admit a vector only if sum_i v_i >= theta (EntryProxyActor.scala:81-93,
                                     max-weight == 1.0 per EntryProxyActor.scala:51-57) */
 #define APSS_FLAG_NORMALIZE 4u   /* L2-normalise rows on ingest (benchmark/LoadGenerator.scala:34-37) */
-#define APSS_FLAG_FORCE_SCAN 8u  /* always use the general accumulator-scan kernel (signed weights path) */
+#define APSS_FLAG_FORCE_SCAN 8u  /* always use the general accumulator-scan kernel (the theta <= 0 path) */
 #define APSS_FLAG_FORCE_GENERAL 16u /* never use the per-wave speed path of the probe (test hook) */
 #define APSS_FLAG_EXACT_ACCUM 32u   /* single-pass join with exact accumulators only: no coarse filter + rescoring pass */
 

@@ -109,9 +109,30 @@ def test_signed_weights_and_nonpositive_threshold(apss_mod, oracle):
     for theta, v in ((0.3, sval), (0.0, val), (-0.2, sval)):
         w = oracle.Worker(dim, theta)
         want = to_map(*w.index_data(np.arange(n), rp, idx, v))
-        got, _ = _gpu_join(apss_mod, dim, theta, rp, idx, v, tile_rows=256)
+        got, st = _gpu_join(apss_mod, dim, theta, rp, idx, v, tile_rows=256)
         assert len(want) > 50
         assert_same_pairs(got, want, theta)
+        # signed weights with theta > 0 still take the two-pass join (the filter sums the positive products only);
+        # theta <= 0 admits pairs of any score: accumulator scan of the general kernel
+        assert (st["filter_survivors"] > 0) == (theta > 0)
+
+
+def test_signed_weights_two_pass_at_scale(apss_mod, oracle):
+    """weights of either sign (a third of the entries flipped, duplicates flip with their source or not) at a density
+    where rounds carry real work; long rows included; candidate pairs counted exactly as for non-negative input"""
+    import scipy.sparse as sp
+    n, dim, nnz, theta = 30_000, 3_000, 24, 0.55
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.3, seed=77, dup_frac=0.15)
+    rng = np.random.default_rng(9)
+    sign_of_term = rng.choice([-1.0, 1.0, 1.0], size=dim)  # a term's sign: near-duplicates keep most of their dot product
+    sval = val * sign_of_term[idx] * rng.choice([-1.0, 1.0], size=val.size, p=[0.05, 0.95])
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, sval))
+    assert len(want) > 2000
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, sval)
+    assert st["filter_survivors"] >= len(want)
+    assert_same_pairs(got, want, theta)
+    X = sp.csr_matrix((np.ones(idx.size, np.float32), idx, rp), shape=(n, dim))
+    assert st["candidate_pairs"] == (X @ X.T).nnz - n
 
 
 def test_streaming_batches_match_oracle_worker(apss_mod, oracle):
