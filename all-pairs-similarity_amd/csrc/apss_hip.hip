@@ -433,8 +433,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const bool cx_fp16_ok = std::sqrt((double)h->store_max_norm2) < 60000.0;  // a weight never exceeds its row's norm
   // (shard mode scales the threshold down per query and tile: the kernel clamps it at 1, which only admits more)
   // weights of either sign with theta > 0 go through the filter too (it then sums positive products only); term shards
-  // and the 65536-row tiles have no such instantiation and keep the general kernel
-  const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !h->sharded && h->cx.cb <= 32768 &&
+  // (and long queries over 65536-row tiles) have no such instantiation and keep the general kernel
+  const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !h->sharded &&
+                         (h->cx.cb <= 32768 || q_max_nnz <= 512) &&
                          !getenv("APSS_CX_CHUNK8") && !getenv("APSS_CX_U3") && !getenv("APSS_CX_U4");
   const bool coarse_path = h->use_coarse && (mode == 0 || cx_signed) && cx_selective && cx_fp16_ok && !forced_general && nq < (1LL << 30) &&
                            !(h->sharded && h->cx.cb > 32768) &&
@@ -582,15 +583,23 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
           auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, true>;
           hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
         }
-      } else if (a.vq_first && cx_signed) {
+      } else if (a.vq_first && cx_signed && !cx_big) {
         auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, true, true>;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
-      } else if (cx_signed) {
+      } else if (cx_signed && !cx_big) {
         auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, false, true>;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
       } else if (a.vq_first) {
         auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, true>;
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
+      } else if (cx_big && cx_signed) {
+        if (cx_big_u3) {
+          auto kern = k_probe_coarse<1024, 3, 256, 1024, false, 16, false, true>;
+          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+        } else {
+          auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, false, true>;
+          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
+        }
       } else if (cx_big) {
         if (cx_big_u3) {
           auto kern = k_probe_coarse<1024, 3, 256, 1024, false>;

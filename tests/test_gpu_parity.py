@@ -351,6 +351,18 @@ def test_maildir_small_plumbing(apss_mod):
     assert_same_pairs(stream, {k: v for k, v in want.items() if k[0] >= (k[1] // 256) * 256}, theta)
 
 
+def test_sparse_regime_with_signed_weights(apss_mod, oracle):
+    """65536-row tiles (1024-thread filter kernel) with weights of either sign"""
+    n, dim, nnz, theta = 70_000, 40_000, 16, 0.6
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=56, dup_frac=0.05)
+    sval = val * np.random.default_rng(3).choice([-1.0, 1.0, 1.0], size=dim)[idx]
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, sval))
+    assert len(want) > 500
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, sval)
+    assert st["tiles"] == 2 and st["filter_survivors"] >= len(want)
+    assert_same_pairs(got, want, theta)
+
+
 def test_sparse_regime_uses_65536_row_tiles(apss_mod, oracle):
     """few postings per (tile, term) segment (C5-like density): the handle picks 65536-row coarse tiles and the
     1024-thread filter kernel; more than one tile, the last one partial"""
