@@ -1297,7 +1297,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const __amdgpu_buffer_rsrc_t rs_po =
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.post_c + pbase), 0, (int)((pend - pbase) * 4), 0x00020000);
   constexpr uint32_t kOob = 0xfffffff0u;
-  constexpr uint32_t kOobStrip = 0xffffff00u;  // + lane offset (< 64 B) stays far outside every posting buffer
 
   for (int i = tid * 4; i < cb / 2 + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 16) ctr[tid] = 0;
@@ -1371,7 +1370,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     f.w = g.w;
     f.tw = wv < r.nnz ? (r.nnz - wv + NW - 1) / NW : 0;
     f.totch = __builtin_amdgcn_readlane((int)incl, kWave - 1);
-    if (ln < WIN) wl[ln] = make_uint2(kOobStrip, 0u);  // empty slot: its posting load is out of range and returns zero
     const uint32_t wbits = __float_as_uint(cxs * g.w);
     auto put = [&](const uint32_t k) {
       if (k < nch && excl + k < (uint32_t)WIN)
@@ -1394,8 +1392,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     for (int u = 0; u < U; ++u) {
       // a posting word of zero is no posting: the padding after a segment's last posting is zero-filled by the build,
       // and an empty slot of the strip holds an out-of-range offset, which reads as zero
+      // a strip slot past the wave's last chunk holds a stale descriptor: its load is sent out of range (-> zero)
       f.wq[u] = __uint_as_float(it[u].y);
-      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, it[u].x + lo * 8u, 0, 0);
+      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, u * GPW + ln / LPC < f.totch ? it[u].x + lo * 8u : kOob, 0, 0);
     }
   };
 
