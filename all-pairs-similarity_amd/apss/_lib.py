@@ -15,7 +15,7 @@ SYMBOLS = [
     "apss_create", "apss_destroy", "apss_last_error", "apss_set_stream", "apss_insert", "apss_query",
     "apss_insert_and_query", "apss_self_join", "apss_result_count", "apss_fetch_results", "apss_size",
     "apss_stats_get", "apss_insert_dev", "apss_query_dev", "apss_insert_and_query_dev", "apss_clear",
-    "apss_results_dev", "apss_partial_scores_dev",
+    "apss_results_dev", "apss_results_copy_dev", "apss_partial_scores_dev",
 ]
 
 
@@ -23,19 +23,21 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("dim", C.c_int32), ("theta", C.c_double),
                 ("index_threshold", C.c_double), ("flags", C.c_uint32), ("device_id", C.c_int32),
                 ("term_lo", C.c_int32), ("term_hi", C.c_int32), ("tile_rows", C.c_int32),
-                ("reserved0", C.c_int32), ("capacity_rows", C.c_int64), ("capacity_nnz", C.c_int64)]
+                ("head_terms", C.c_int32), ("capacity_rows", C.c_int64), ("capacity_nnz", C.c_int64)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("tiles", C.c_int64), ("posting_visits", C.c_int64),
                 ("candidate_pairs", C.c_int64), ("result_pairs", C.c_int64), ("probe_ms", C.c_double),
                 ("build_ms", C.c_double), ("probe_launches", C.c_int64), ("hbm_bytes", C.c_int64),
-                ("filter_survivors", C.c_int64), ("rescore_ms", C.c_double)]
+                ("filter_survivors", C.c_int64), ("rescore_ms", C.c_double),
+                ("head_terms", C.c_int64), ("head_pairs", C.c_int64), ("head_survivors", C.c_int64),
+                ("head_ms", C.c_double), ("head_flops", C.c_double)]
 
 
 def build(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  In-tree output, travels with gpurun."""
-    srcs = [os.path.join(CSRC, f) for f in ("apss_hip.hip", "apss_kernels.hpp")] + [
+    srcs = [os.path.join(CSRC, f) for f in ("apss_hip.hip", "apss_kernels.hpp", "apss_head.hpp")] + [
         os.path.normpath(os.path.join(CSRC, "..", "..", "include", "apss.h"))]
     if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return SO_PATH
@@ -101,6 +103,8 @@ def lib():
     L.apss_clear.argtypes = [vp]
     L.apss_results_dev.restype = i32
     L.apss_results_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), pi64]
+    L.apss_results_copy_dev.restype = i32
+    L.apss_results_copy_dev.argtypes = [vp, i64, i64, vp, vp, vp]
     L.apss_partial_scores_dev.restype = i32
     L.apss_partial_scores_dev.argtypes = [vp, i64, vp, vp, vp]
     _lib = L

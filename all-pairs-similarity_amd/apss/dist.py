@@ -6,16 +6,17 @@ lets each worker recompute the whole dot product (SparseVectorWrapper.scala:9). 
 term RANGE, stores only that slice of every vector, and the exact score is assembled from per-shard partials:
 
   1. local (no communication): shard g probes its slice and keeps the CANDIDATES, pairs whose partial p_g satisfies
-     p_g >= theta * |q_g| * |c_g|  (|x_g| = L2 norm of x restricted to g's terms).  If sum_g p_g >= theta then, since
-     p_g <= |q_g||c_g| and sum_g |q_g||c_g| <= |q||c| <= 1 (Cauchy-Schwarz twice, unit-norm inputs), at least one
-     shard passes the test: no true pair is lost, and random pairs (one shared term) almost never pass.
+     p_g >= theta * |q_g||c_g| / (|q||c|)  (|x_g| = L2 norm of x restricted to g's terms, |x| = norm of the whole row;
+     the library stores the ratios |x_g| / |x| at ingest).  If sum_g p_g >= theta then, since p_g <= |q_g||c_g| and
+     sum_g |q_g||c_g| <= |q||c| (Cauchy-Schwarz twice), at least one shard passes the test -- whatever the row norms
+     and the signs of the weights: no true pair is lost, and random pairs (one shared term) almost never pass.
   2. all-gather of the candidate lists (a few MB at most), union;
   3. every shard computes its exact partial for every candidate (apss_partial_scores_dev);
   4. ONE all-reduce(SUM) of the per-candidate partial scores over RCCL, then the `>= theta` prune (IWA:93).
 
 A dense all-reduce of per-query accumulators would move 4*N bytes per query (~50x slower than
-the single-GPU join); this exchange moves O(#near-pairs).  Requires ||x|| <= 1 (the reference's own precondition:
-CommonUtils.scala:88 "assuming the normalized vectors").
+the single-GPU join); this exchange moves O(#near-pairs).  No precondition on the norms (the reference assumes
+normalised vectors, CommonUtils.scala:88; un-normalised input gives the same pairs as the single-GPU join).
 
 The compute engine is injected so the host logic can be exercised on CPU with gloo in tests (tests/ provides an
 engine backed by the CPU oracle); the product engine below is HIP-only.
@@ -81,11 +82,15 @@ class HipShardEngine:
 
     def candidates(self):
         """phase 1: rebuild the shard's index and return its candidate pairs (query row, candidate row), global rows"""
-        self.join()
-        q, c, sc = self.ix.fetch()  # external ids == global row numbers
-        self.stats = self.ix.stats()
+        n = self.join()
+        # the lists stay in HBM: (query row, candidate slot) copied device-to-device into torch tensors on the same stream
+        q = torch.empty(n, dtype=torch.int32, device=self.device)
+        c = torch.empty(n, dtype=torch.int32, device=self.device)
+        sc = torch.empty(n, dtype=torch.float32, device=self.device)
+        if n:
+            self.ix.results_to(q, c, sc)
         self.scores = sc  # final scores when the handle holds the whole term space (T == 1)
-        return (torch.from_numpy(q).to(self.device), torch.from_numpy(c).to(self.device))
+        return q.to(torch.int64), c.to(torch.int64) + self.r0  # query row == global row; slot -> global candidate row
 
     def partial(self, q_row, c_row):
         out = torch.empty(q_row.numel(), dtype=torch.float32, device=self.device)
@@ -190,7 +195,7 @@ class ShardedJoin:
             uq, uc, sizes = q, c, [int(q.numel())]
             uniq = q
             sc = getattr(self.engine, "scores", None)
-            part = torch.from_numpy(np.asarray(sc, dtype=np.float32)).to(self.device) if sc is not None \
+            part = torch.as_tensor(sc, dtype=torch.float32, device=self.device) if sc is not None \
                 else self.engine.partial(uq, uc)
             keep = torch.ones(q.numel(), dtype=torch.bool, device=self.device) if sc is not None else part >= self.theta
         else:

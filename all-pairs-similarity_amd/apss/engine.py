@@ -26,7 +26,7 @@ def _ptr(a):
 
 class ApssIndex:
     def __init__(self, dim, theta, device=0, tile_rows=0, term_range=None, flags=0, index_threshold=0.0,
-                 capacity_rows=0, capacity_nnz=0):
+                 capacity_rows=0, capacity_nnz=0, head_terms=0):
         L = _lib.lib()
         cfg = _lib.Config()
         cfg.struct_size = C.sizeof(_lib.Config)
@@ -37,6 +37,7 @@ class ApssIndex:
         cfg.device_id = int(device)
         cfg.term_lo, cfg.term_hi = (0, 0) if term_range is None else (int(term_range[0]), int(term_range[1]))
         cfg.tile_rows = int(tile_rows)
+        cfg.head_terms = int(head_terms)  # dense-head block: 0 auto, -1 never, 64 | 128 | 256 forced
         cfg.capacity_rows = int(capacity_rows)
         cfg.capacity_nnz = int(capacity_nnz)
         h = C.c_void_p()
@@ -164,6 +165,12 @@ class ApssIndex:
         a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(0)
         self._chk(self._L.apss_results_dev(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
         return a.value, b.value, c.value, n.value
+
+    def results_to(self, q_row=None, c_slot=None, score=None, offset=0):
+        """copy the last results into torch device tensors (int32, int32, float32) without leaving the GPU"""
+        n = max(t.numel() for t in (q_row, c_slot, score) if t is not None)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)  # noqa: E731
+        self._chk(self._L.apss_results_copy_dev(self._h, offset, n, ptr(q_row), ptr(c_slot), ptr(score)))
 
     def partial_scores_dev(self, q_row, c_slot, out):
         import torch

@@ -15,6 +15,10 @@ CONFIGS = {
     "c3z": dict(n=1_000_000, dim=100_000, nnz=100, zipf_s=0.5, theta=0.8, seed=20242),
     "c5": dict(n=10_000_000, dim=1_000_000, nnz=200, zipf_s=0.0, theta=0.9, seed=20244),
     "c5s": dict(n=2_000_000, dim=1_000_000, nnz=200, zipf_s=0.0, theta=0.9, seed=20244),  # C5 shape at one fifth of N
+    # skewed variants drawn by make_vectors_zipf_dev (device-side generator; the per-row host loop of make_vectors
+    # needs minutes per million rows): C3 with Zipf(1) terms, and BASELINE.json configs[4] "power-law" at one fifth of N
+    "c3z1": dict(n=1_000_000, dim=100_000, nnz=100, zipf_s=1.0, theta=0.8, seed=20243, gen="zipf_dev"),
+    "c5z": dict(n=2_000_000, dim=1_000_000, nnz=200, zipf_s=1.0, theta=0.9, seed=20245, gen="zipf_dev"),
 }
 
 
@@ -85,11 +89,16 @@ def make_vectors(n, dim, nnz, zipf_s=0.0, seed=0, dup_frac=0.05):
     return rowptr, idx.reshape(-1).astype(np.int32), val.reshape(-1).astype(np.float64)
 
 
-def make_config(name, n=None):
-    """One of BASELINE.json's synthetic configs (optionally truncated to the first n rows' worth)."""
+def make_config(name, n=None, device=None):
+    """One of BASELINE.json's synthetic configs (optionally with n rows instead of the config's) as host CSR."""
     c = dict(CONFIGS[name])
     if n is not None:
         c["n"] = n
+    if c.get("gen") == "zipf_dev":
+        import torch
+        dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+        rp, idx, val = make_vectors_zipf_dev(c["n"], c["dim"], c["nnz"], c["zipf_s"], c["seed"], dev)
+        return c, rp.cpu().numpy(), idx.reshape(-1).cpu().numpy(), val.reshape(-1).double().cpu().numpy()
     rowptr, idx, val = make_vectors(c["n"], c["dim"], c["nnz"], c["zipf_s"], c["seed"])
     return c, rowptr, idx, val
 
@@ -153,3 +162,73 @@ def stratified_dot(idx, val, a, b, block=1 << 20):
         x, y = a[k0:k0 + block], b[k0:k0 + block]
         out[k0:k0 + block] = ((idx[x] == idx[y]) * (val[x].double() * val[y].double())).sum(dim=1)
     return out
+
+
+def make_vectors_zipf_dev(n, dim, nnz, zipf_s, seed, device, dup_frac=0.05, block=1 << 16):
+    """Zipf(s) workload drawn with torch on `device` (the GPU for the million-row configs; "cpu" works for tests).
+
+    Per row: 3 * nnz draws with replacement from p_t ~ 1 / rank^s (term ids randomly permuted), the first nnz DISTINCT
+    ones in draw order are the row's terms (rows short of nnz distinct draws -- rare -- draw again, 16x as many);
+    values |N(0,1)| + 0.05; planted near-duplicates as in make_vectors (10 % of the terms replaced by uniformly drawn
+    ones that the row does not hold yet, values x U(0.9, 1.1)); rows L2-normalised (benchmark/LoadGenerator.scala:34-37).
+    Returns torch tensors (rowptr int64[n+1], idx int32[n, nnz] ascending per row, val float32[n, nnz])."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    p = 1.0 / torch.arange(1, dim + 1, dtype=torch.float64, device=device) ** zipf_s
+    cdf = torch.cumsum(p / p.sum(), 0)
+    perm = torch.randperm(dim, generator=g, device=device).to(torch.int32)
+
+    def draw_rows(m, over):
+        L = nnz * over
+        d = torch.searchsorted(cdf, torch.rand((m, L), generator=g, device=device, dtype=torch.float64)).clamp_(max=dim - 1)
+        order = torch.argsort(d, dim=1, stable=True)
+        ds = torch.gather(d, 1, order)
+        first = torch.ones_like(ds, dtype=torch.bool)
+        first[:, 1:] = ds[:, 1:] != ds[:, :-1]
+        isfirst = torch.zeros_like(first).scatter_(1, order, first)  # first occurrence, in draw order
+        keep = isfirst & (torch.cumsum(isfirst, 1) <= nnz)
+        return d, keep, keep.sum(1)
+
+    idx = torch.empty((n, nnz), dtype=torch.int32, device=device)
+    for r0 in range(0, n, block):
+        m = min(n, r0 + block) - r0
+        d, keep, cnt = draw_rows(m, 3)
+        ok = cnt == nnz
+        out = torch.empty((m, nnz), dtype=torch.int64, device=device)
+        out[ok] = d[ok][keep[ok]].view(-1, nnz)
+        bad = (~ok).nonzero().flatten()
+        while bad.numel():
+            d2, keep2, cnt2 = draw_rows(bad.numel(), 48)
+            ok2 = cnt2 == nnz
+            out[bad[ok2]] = d2[ok2][keep2[ok2]].view(-1, nnz)
+            bad = bad[~ok2]
+        idx[r0:r0 + m] = torch.sort(perm[out], dim=1).values
+    val = torch.randn((n, nnz), generator=g, device=device).abs_() + 0.05
+
+    if dup_frac > 0 and n > 1:
+        is_dup = torch.rand(n, generator=g, device=device) < dup_frac
+        is_dup[0] = False
+        rows = is_dup.nonzero().flatten()
+        cand = (torch.rand(rows.numel(), generator=g, device=device, dtype=torch.float64) * rows.to(torch.float64)).to(torch.int64)
+        last_base = torch.where(~is_dup, torch.arange(n, device=device), torch.zeros((), dtype=torch.int64, device=device))
+        src = torch.cummax(last_base, 0).values[cand]  # nearest base (non-duplicate) row at or before the drawn one
+        n_rep = max(1, nnz // 10)
+        for b0 in range(0, rows.numel(), block):
+            rr, ss = rows[b0:b0 + block], src[b0:b0 + block]
+            m = rr.numel()
+            t = idx[ss].clone()
+            v = val[ss] * (0.9 + 0.2 * torch.rand((m, nnz), generator=g, device=device))
+            pos = torch.argsort(torch.rand((m, nnz), generator=g, device=device), dim=1)[:, :n_rep]
+            new_t = torch.randint(0, dim, (m, n_rep), generator=g, device=device, dtype=torch.int32)
+            # a replacement that the row already holds (or that repeats inside the draw) is skipped
+            clash = (new_t[:, :, None] == t[:, None, :]).any(2)
+            clash |= torch.triu(new_t[:, :, None] == new_t[:, None, :], diagonal=1).any(1)
+            cur = torch.gather(t, 1, pos)
+            t.scatter_(1, pos, torch.where(clash, cur, new_t))
+            order = torch.argsort(t, dim=1, stable=True)
+            idx[rr] = torch.gather(t, 1, order)
+            val[rr] = torch.gather(v, 1, order)
+    val /= val.norm(dim=1, keepdim=True)
+    rowptr = torch.arange(0, (n + 1) * nnz, nnz, dtype=torch.int64, device=device)
+    return rowptr, idx, val

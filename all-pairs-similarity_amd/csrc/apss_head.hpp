@@ -1,0 +1,449 @@
+// apss_head.hpp -- dense-head path of the probe (gfx950 / CDNA4 MFMA).
+//
+// Under a skewed term distribution (TF-IDF is Zipfian) a few terms occur in a large fraction of the vectors: their
+// posting lists are N long and the inverted-index probe (IndexingWorkerActor.scala:101-109) visits df_t^2 postings for
+// each of them.  Those terms are taken OUT of the inverted index and kept as a dense block instead: row c of
+//     W [rows x KH]  (bf16),   w_c = c_H * |c| / |c_H|     (c_H = the row restricted to the KH head terms)
+// so that  w_q . w_c = cos_H(q, c) * |q| |c|.  The arithmetic is the reference's dot product
+// (CommonUtils.scala:110-115) restricted to the head dims, as a [queries x KH] x [KH x candidates] bf16 contraction
+// on the matrix cores.
+//
+// How the two halves are joined (exact, no pair lost).  Split every vector into head and tail part.  For a pair with
+// q.c >= theta:  q.c = p_H + p_T,  p_g <= |q_g||c_g|,  |q_H||c_H| + |q_T||c_T| <= |q||c|  (Cauchy-Schwarz twice), hence
+//     p_H >= theta |q_H||c_H| / (|q||c|)   or   p_T >= theta |q_T||c_T| / (|q||c|)
+// (if both failed, the sum would stay below theta).  The first test is  w_q . w_c >= theta  -- k_head_gemm, a FILTER in
+// bf16 whose threshold is lowered by the rounding bound below; the second is the term-shard rule of the sparse filter
+// (k_probe_coarse<SHARD> with the ratios |x_T|/|x| as scales).  The union of both candidate lists (k_pair_dedup) is
+// re-scored exactly over the FULL rows by k_rescore (CommonUtils.scala:98-117) and pruned at theta
+// (IndexingWorkerActor.scala:93), exactly as the survivors of the plain two-pass join are.
+//
+// Rounding bound of the contraction: bf16 keeps 8 significant bits, round-to-nearest errs by <= 2^-8 relative, a
+// product of two rounded factors by <= 2^-7 + 2^-16, and sum_i |a_i b_i| <= |a||b| <= B (B = the largest |q||c| of the
+// call), so |bf16 dot - exact| <= 0.00783 B; the fp32 accumulation of <= 256 products adds < 2e-5 B.  The host
+// passes thr = theta - 0.0080 B.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "apss_kernels.hpp"
+
+namespace apss {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 apss_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float apss_f32x16;
+
+constexpr int kHeadQBlock = 512;   // query slots per workgroup (8 waves x 64)
+constexpr int kHeadCTile = 64;     // candidate rows per LDS tile
+constexpr uint32_t kNoTerm = 0x7fffffffu;  // idx_tail value of an entry that lives in the dense block
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rn(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);  // finite inputs only (ingest rejects the rest)
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sampled document frequencies of the store (row r counts iff r % stride == 0): the head-term policy only needs the
+// shape of the distribution, and a full histogram would be 1e8 same-line global atomics per C3 step
+__global__ void k_df_sample(const int64_t *rowptr, const int32_t *idx, int64_t n_rows, int64_t stride, uint32_t *df) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int lane = threadIdx.x % kWave;
+  const int64_t row = wave * stride;
+  if (row >= n_rows) return;
+  const int64_t b = rowptr[row], e = rowptr[row + 1];
+  for (int64_t k = b + lane; k < e; k += kWave) atomicAdd(&df[idx[k]], 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_head_pack: one wave per row of a CSR batch -> its row of W, its tail ratio |x_T| / |x| (the scale of the sparse
+// filter's shard rule), and (store rows) the entry-wise term array the index build reads, head entries masked out.
+struct HeadPackArgs {
+  const int64_t *rowptr;   // absolute offsets into idx / val
+  const int32_t *idx;
+  const float *val;
+  int64_t row0, row1;      // rows [row0, row1) of that CSR
+  const int32_t *head_pos; // [dim] position of a term in the dense block, -1 = tail term
+  int32_t kh;              // 64 | 128 | 256
+  uint16_t *W;             // [.. x kh] bf16 bits; row r is written at W + (w_row0 + r - row0) * kh
+  int64_t w_row0;
+  float *ratio_t;          // [..] |x_T| / |x| per row, same indexing as W rows
+  int32_t *idx_tail;       // same extent as idx (may be null): idx with head entries replaced by kNoTerm
+  unsigned int *head_nonempty;  // += rows with at least one head entry
+};
+
+__global__ __launch_bounds__(256) void k_head_pack(HeadPackArgs a) {
+  __shared__ uint16_t rowbuf[4][256];
+  __shared__ unsigned int nz;
+  if (threadIdx.x == 0) nz = 0;
+  __syncthreads();
+  const int wv = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int64_t row = a.row0 + (int64_t)blockIdx.x * 4 + wv;
+  if (row < a.row1) {
+    const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
+    float full2 = 0.f, h2 = 0.f, t2 = 0.f;
+    for (int64_t k = b + lane; k < e; k += kWave) {
+      const float v = a.val[k];
+      const int32_t t = a.idx[k];
+      const int32_t hp = a.head_pos[t];
+      full2 += v * v;
+      if (hp >= 0) h2 += v * v; else t2 += v * v;
+      if (a.idx_tail) a.idx_tail[k] = hp >= 0 ? (int32_t)kNoTerm : t;
+    }
+    for (int o = kWave / 2; o; o >>= 1) {
+      full2 += __shfl_xor(full2, o);
+      h2 += __shfl_xor(h2, o);
+      t2 += __shfl_xor(t2, o);
+    }
+    const float scale = h2 > 0.f ? sqrtf(full2 / h2) : 0.f;
+    for (int i = lane; i < a.kh; i += kWave) rowbuf[wv][i] = 0;
+    // (LDS operations of one wave execute in order: the zero fill lands before the entries, the read-out after them)
+    for (int64_t k = b + lane; k < e; k += kWave) {
+      const int32_t hp = a.head_pos[a.idx[k]];
+      if (hp >= 0) rowbuf[wv][hp] = f32_to_bf16_rn(a.val[k] * scale);
+    }
+    const int64_t wr = a.w_row0 + (row - a.row0);
+    uint16_t *dst = a.W + wr * a.kh;
+    for (int i = lane * 2; i < a.kh; i += kWave * 2)
+      *reinterpret_cast<uint32_t *>(dst + i) = *reinterpret_cast<const uint32_t *>(&rowbuf[wv][i]);
+    if (lane == 0) {
+      // rounded UP a hair: the scale only ever lowers the sparse filter's threshold
+      a.ratio_t[wr] = full2 > 0.f ? fminf(1.0f, sqrtf(t2 / full2) * 1.000001f) : 0.f;
+      if (h2 > 0.f) atomicAdd(&nz, 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && nz && a.head_nonempty) atomicAdd(a.head_nonempty, nz);
+}
+
+// zero rows [r0, r1) of a [.. x kh] bf16 matrix (the padding a GEMM tile may read past the last row)
+__global__ void k_head_zero_rows(uint16_t *W, int64_t r0, int64_t r1, int32_t kh) {
+  const int64_t n = (r1 - r0) * kh / 8;  // uint4 = 8 bf16
+  uint4 *p = reinterpret_cast<uint4 *>(W + r0 * kh);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_head_gemm: the dense-head filter.  D[q][c] = w_q . w_c for a block of 512 query slots against a panel of candidate
+// rows, v_mfma_f32_32x32x16_bf16; nothing of D is stored: every element is compared with thr in registers and the few
+// that pass are appended to the candidate list (wavefront ballot + prefix count, one global atomic per wave).
+//
+// Shape.  One workgroup = 8 waves = 512 query slots; wave w keeps the A fragments of its 64 slots (2 x KH/16 fragments
+// of 8 bf16 = 128 VGPRs at KH = 256) in registers for the whole kernel and the panel's candidate rows stream past it:
+// tiles of 64 candidates x KH (32 KB at KH = 256) are copied global -> LDS by LDS-DMA (buffer -> lds, 16 B per lane,
+// 1 KiB per wave-instruction) into two buffers, tile t + 1 in flight while the 64 MFMAs of tile t run; one barrier per
+// tile.  The LDS image is linear in DMA order (the destination is wave-uniform base + lane * 16), so the bank swizzle
+// sits on the SOURCE address: LDS chunk (row, p) holds source chunk p ^ s(row), and a fragment read of 16 lanes (16 rows,
+// the same k) then covers all 64 banks once.
+// Grid: blockIdx -> (panel = blockIdx % P, query block descending).  Hardware sends consecutive workgroups to
+// consecutive XCDs, so with P a multiple of 8 every workgroup of an XCD streams a panel of the same residue class: the
+// panel's tiles are read from HBM once per XCD and then served by that XCD's L2 to the other workgroups sweeping it.
+// Stored queries (self-join, insert-and-query): D is symmetric over the batch, so candidate tiles ABOVE a query block
+// are skipped and an element strictly below it reports both (q, c) and (c, q).
+struct HeadGemmArgs {
+  const uint16_t *Wq;   // query rows: indexed by query SLOT when the batch is stored (Wq == Wc), else by query row
+  const uint16_t *Wc;   // candidate rows by slot, zero rows up to the tile boundary
+  int64_t wq_rows;      // rows of Wq that may be read
+  int64_t n_rows;       // candidate slots
+  int64_t q_slot_base;  // slot of query row 0 when the batch is stored in the index, else -1
+  int32_t nq;
+  int32_t n_qblocks, n_panels, tiles_per_panel, n_ctiles;
+  int64_t qblock0;      // first query block's first slot (a multiple of 512)
+  const int64_t *q_ext, *c_ext;
+  float thr;
+  int32_t *res_q, *res_c;
+  float *res_s;
+  uint64_t res_cap;
+  unsigned long long *counters;    // [kCtrResults] shared with the sparse filter
+  unsigned long long *head_pairs;  // += elements with a positive dot (pairs sharing a head term), self pairs included
+};
+
+template <int KH>
+__global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
+  constexpr int KS = KH / 16;                 // k-steps of the 32x32x16 MFMA
+  constexpr int ROWB = KH * 2;                // bytes per row
+  constexpr int CPR = KH / 8;                 // 16-B chunks per row
+  constexpr int TILEB = kHeadCTile * ROWB;    // bytes per LDS tile
+  constexpr int PIECES = TILEB / 1024;        // 1-KiB DMA pieces per tile
+  constexpr int PPW = PIECES / 8;             // pieces per wave
+  static_assert(PIECES % 8 == 0, "every wave copies the same number of pieces");
+  __shared__ __attribute__((aligned(1024))) unsigned char ldsb[2 * TILEB];
+  __shared__ float scratch[8 * 16 * kWave];  // reporting path only: one 32 x 32 accumulator block per wave
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
+  const int r = ln & 31, hh = ln >> 5;
+  const int panel = blockIdx.x % a.n_panels;
+  const int qb = a.n_qblocks - 1 - (int)(blockIdx.x / a.n_panels);
+  const bool stored = a.q_slot_base >= 0;
+  const int64_t B0 = a.qblock0 + (int64_t)qb * kHeadQBlock;  // first query slot of this block
+  const int64_t qs0 = stored ? a.q_slot_base : 0;            // slot of query row 0
+
+  int t_lo = panel * a.tiles_per_panel;
+  int t_hi = min(a.n_ctiles, t_lo + a.tiles_per_panel);
+  if (stored) t_hi = min(t_hi, (int)((B0 + kHeadQBlock) / kHeadCTile));  // tiles above the block: done by the block that owns them
+  if (t_lo >= t_hi) return;
+
+  // ---- A fragments: lane (r, hh) of block m holds W[slot][16 kk + 8 hh .. + 8) ----
+  apss_bf16x8 af[2][KS];
+  const int64_t wslot0 = B0 + 64 * wv;
+  bool wave_live = false;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int64_t s = wslot0 + 32 * m + r;
+    const int64_t row = s - qs0;
+    const bool ok = row >= 0 && row < a.nq && s < a.wq_rows;
+    wave_live |= ok;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq + (ok ? s : 0) * KH) + hh;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) v = src[2 * kk];
+      af[m][kk] = __builtin_bit_cast(apss_bf16x8, v);
+    }
+  }
+  wave_live = __any(wave_live);  // a wave without a query row copies tiles but computes nothing
+
+  // ---- tile copy: wave w moves pieces w * PPW .. of the tile; LDS chunk g = piece * 64 + lane <- source chunk ----
+  auto swz = [](int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & (CPR - 1)); };
+  uint32_t src_off[PPW];  // byte offset of this lane's source chunk inside a tile
+#pragma unroll
+  for (int p = 0; p < PPW; ++p) {
+    const int g = (wv * PPW + p) * 64 + ln;
+    const int row = g / CPR, pc = g % CPR;
+    src_off[p] = (uint32_t)(row * ROWB + ((pc ^ swz(row)) & (CPR - 1)) * 16);
+  }
+  auto copy_tile = [&](const int t, const int buf) {
+    const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * TILEB;
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(tsrc + src_off[p]),
+          (__attribute__((address_space(3))) void *)(ldsb + buf * TILEB + (wv * PPW + p) * 1024), 16, 0, 0);
+    }
+  };
+  // fragment read offsets: lane (r, hh) of column block n reads row 32 n + r, chunk (2 kk + hh) ^ s(row)
+  uint32_t rd_row[2], rd_sw[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int row = 32 * n + r;
+    rd_row[n] = (uint32_t)(row * ROWB);
+    rd_sw[n] = (uint32_t)swz(row);
+  }
+
+  uint32_t n_pos = 0;  // positive elements seen by this lane (< 2^32: at most 128 per tile)
+  copy_tile(t_lo, 0);
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int buf = (t - t_lo) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
+    __syncthreads();                                   // ... and everyone's; the other buffer's readers are done
+    if (t + 1 < t_hi) copy_tile(t + 1, buf ^ 1);
+    if (!wave_live) continue;
+
+    apss_f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    const unsigned char *tb = ldsb + buf * TILEB;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      apss_bf16x8 bf[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const uint32_t chunk = ((uint32_t)(2 * kk + hh) ^ rd_sw[n]) & (uint32_t)(CPR - 1);
+        bf[n] = __builtin_bit_cast(apss_bf16x8, *reinterpret_cast<const uint4 *>(tb + rd_row[n] + chunk * 16u));
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][kk], bf[n], acc[m][n], 0, 0, 0);
+    }
+
+    // ---- epilogue: nothing is stored; count the positive elements, find the few at or above the threshold ----
+    const int64_t c_row0 = (int64_t)t * kHeadCTile;
+    // strictly below the query block (and inside the stored batch): the mirrored element is computed by nobody
+    const bool below = stored && c_row0 + kHeadCTile <= B0;
+    float mx = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      uint32_t pos = 0;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          mx = fmaxf(mx, acc[m][n][i]);
+          pos += acc[m][n][i] > 0.f ? 1u : 0u;
+        }
+      // an element below the block stands for (q, c) and, when c is itself a query of the batch, for (c, q) too
+      n_pos += (below && c_row0 + 32 * n + r >= qs0) ? 2u * pos : pos;
+    }
+
+    if (__any(mx >= a.thr)) {
+      // rare (a tile holding a near-duplicate, or the block's own diagonal): the wave's accumulators go through a
+      // wave-private LDS scratch one 32 x 32 block at a time, so that the reporting loop is a real loop
+      float *sc = scratch + wv * (16 * kWave);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sc[i * kWave + ln] = acc[m][n][i];
+          const int64_t c = c_row0 + 32 * n + r;
+          const int64_t cext = c < a.n_rows ? a.c_ext[c] : 0;
+#pragma unroll 1
+          for (int i = 0; i < 16; ++i) {
+            const float v = sc[i * kWave + ln];
+            if (!__any(v >= a.thr)) continue;
+            const int64_t s = wslot0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int64_t qrow = s - qs0;
+            bool ok = v >= a.thr && qrow >= 0 && qrow < a.nq && c < a.n_rows;
+            if (ok) ok = a.q_ext[qrow] != cext;  // self-exclusion by external id (IWA:91)
+            const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+            if (ok && o < a.res_cap) {
+              a.res_q[o] = (int32_t)qrow;
+              a.res_c[o] = (int32_t)c;
+              a.res_s[o] = v;  // filter score; k_rescore replaces it
+            }
+            const bool ok2 = ok && below && c >= qs0;  // the mirrored pair: c as the query, q's slot as the candidate
+            const uint64_t o2 = wave_append(ok2, &a.counters[kCtrResults]);
+            if (ok2 && o2 < a.res_cap) {
+              a.res_q[o2] = (int32_t)(c - qs0);
+              a.res_c[o2] = (int32_t)s;
+              a.res_s[o2] = v;
+            }
+          }
+        }
+    }
+  }
+  // positive elements seen by this wave -> one atomic
+  unsigned long long tot = n_pos;
+  for (int o = kWave / 2; o; o >>= 1) tot += __shfl_xor(tot, o);
+  if (ln == 0 && tot) atomicAdd(a.head_pairs, tot);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_head_gemv: the same filter for a query batch too small to fill 32-row MFMA blocks (single-vector messages of the
+// latency path, benchmark/LoadGenerator.scala:58-74): HBM-bound sweep of W, 8 lanes per candidate row, the query
+// vectors (<= 8 per launch group) in LDS as fp32.
+struct HeadGemvArgs {
+  const uint16_t *Wq;
+  const uint16_t *Wc;
+  int64_t n_rows;
+  int64_t q_slot_base;
+  int32_t nq;
+  int32_t kh;
+  const int64_t *q_ext, *c_ext;
+  float thr;
+  int32_t *res_q, *res_c;
+  float *res_s;
+  uint64_t res_cap;
+  unsigned long long *counters;
+  unsigned long long *head_pairs;
+};
+
+constexpr int kGemvQ = 8;  // queries per pass over W
+
+__global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
+  __shared__ float qv[kGemvQ][256];
+  __shared__ unsigned long long npos;
+  const int tid = threadIdx.x, ln = tid % kWave;
+  const int j = ln & 7;  // this lane's 16-B chunk inside a group of 8 lanes
+  const int64_t qs0 = a.q_slot_base >= 0 ? a.q_slot_base : 0;
+  const int cpr = a.kh / 8;
+  if (tid == 0) npos = 0;
+  unsigned long long my_pos = 0;
+  for (int q0 = 0; q0 < a.nq; q0 += kGemvQ) {
+    const int nqq = min(kGemvQ, a.nq - q0);
+    __syncthreads();
+    for (int i = tid; i < nqq * a.kh; i += blockDim.x) {
+      const int qq = i / a.kh, k = i % a.kh;
+      const uint16_t b = a.Wq[(qs0 + q0 + qq) * a.kh + k];
+      qv[qq][k] = __uint_as_float((uint32_t)b << 16);
+    }
+    __syncthreads();
+    // 8 candidate rows per wave step, 4 waves per workgroup, grid-stride over the rows
+    for (int64_t c0 = ((int64_t)blockIdx.x * 4 + tid / kWave) * 8; c0 < a.n_rows; c0 += (int64_t)gridDim.x * 32) {
+      const int64_t c = c0 + (ln >> 3);
+      float s[kGemvQ];
+#pragma unroll
+      for (int qq = 0; qq < kGemvQ; ++qq) s[qq] = 0.f;
+      if (c < a.n_rows) {
+        const uint4 *rowp = reinterpret_cast<const uint4 *>(a.Wc + c * a.kh);
+        for (int ch = j; ch < cpr; ch += 8) {
+          const uint4 v = rowp[ch];
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+#pragma unroll
+            for (int qq = 0; qq < kGemvQ; ++qq)
+              if (qq < nqq) s[qq] += lo * qv[qq][ch * 8 + 2 * e] + hi * qv[qq][ch * 8 + 2 * e + 1];
+          }
+        }
+      }
+#pragma unroll
+      for (int qq = 0; qq < kGemvQ; ++qq) {
+        s[qq] += __shfl_xor(s[qq], 1);
+        s[qq] += __shfl_xor(s[qq], 2);
+        s[qq] += __shfl_xor(s[qq], 4);
+      }
+#pragma unroll
+      for (int qq = 0; qq < kGemvQ; ++qq) {
+        if (qq >= nqq) break;
+        const bool lead = j == 0 && c < a.n_rows;
+        if (lead && s[qq] > 0.f) my_pos++;
+        bool ok = lead && s[qq] >= a.thr;
+        if (ok) ok = a.q_ext[q0 + qq] != a.c_ext[c];
+        const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+        if (ok && o < a.res_cap) {
+          a.res_q[o] = q0 + qq;
+          a.res_c[o] = (int32_t)c;
+          a.res_s[o] = s[qq];
+        }
+      }
+    }
+  }
+  if (my_pos) atomicAdd(&npos, my_pos);
+  __syncthreads();
+  if (tid == 0 && npos) atomicAdd(a.head_pairs, npos);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_pair_dedup: the two filters report a pair that passes both tests twice; keep one.  Open-addressing hash set of
+// 64-bit keys (q << 32 | c) in global memory, one atomicCAS per probe; the table holds >= 2x the pairs, so a probe
+// sequence always ends at an empty slot.
+__global__ void k_pair_dedup(const int32_t *in_q, const int32_t *in_c, const float *in_s, int64_t n,
+                             unsigned long long *table, uint64_t mask, int32_t *out_q, int32_t *out_c, float *out_s,
+                             unsigned long long *out_count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool keep = false;
+  int32_t q = 0, c = 0;
+  if (i < n) {
+    q = in_q[i];
+    c = in_c[i];
+    const unsigned long long key = ((unsigned long long)(uint32_t)q << 32) | (uint32_t)c;  // never ~0: q < 2^31
+    unsigned long long x = key * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    uint64_t hpos = x & mask;
+    for (uint64_t step = 0; step <= mask; ++step) {
+      const unsigned long long old = atomicCAS(&table[hpos], ~0ull, key);
+      if (old == ~0ull) {
+        keep = true;
+        break;
+      }
+      if (old == key) break;
+      hpos = (hpos + 1) & mask;
+    }
+  }
+  const uint64_t o = wave_append(keep, out_count);
+  if (keep) {
+    out_q[o] = q;
+    out_c[o] = c;
+    out_s[o] = in_s[i];
+  }
+}
+
+}  // namespace apss

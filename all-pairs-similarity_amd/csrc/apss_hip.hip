@@ -16,6 +16,7 @@
 
 #include "../../include/apss.h"
 #include "apss_kernels.hpp"
+#include "apss_head.hpp"
 
 using namespace apss;
 
@@ -29,10 +30,58 @@ struct DevBuf {
   size_t cap = 0;  // elements
 };
 
+// Test and experiment hooks: ONE environment word, APSS_DEBUG, read once when a handle is created -- a comma-separated
+// list of the tokens below.  Nothing else in the library reads the environment.
+struct DebugCfg {
+  bool build_lds = false;      // build_lds      index build with LDS cursors even for a handful of tiles
+  bool build_atomic = false;   // build_atomic   index build with global atomics even for small dims
+  bool chunk8 = false;         // chunk8         filter kernel with 8-posting chunks (4-step window)
+  bool shard_exact = false;    // shard_exact    term-range shards run the single-pass exact kernel
+  bool diag = false;           // diag           in-kernel cycle stamps of the single-pass kernel (stderr)
+  bool force_general = false;  // force_general  as APSS_FLAG_FORCE_GENERAL
+  bool exact_accum = false;    // exact_accum    as APSS_FLAG_EXACT_ACCUM, decided per probe
+  bool big_u5 = false;         // big_u5         1024-thread filter kernel keeps its 5-step window
+  int cx_tile = 0;             // cx_tile=N      rows per tile of the coarse index (multiple of 64, <= 65536)
+  int window = 0;              // window=U       register-window steps of the 512-thread filter kernel (2..5)
+  int chunks = 0;              // chunks=N       query chunks per tile (grid shape)
+  int tiles_per_launch = 0;    // tiles_per_launch=N
+};
+
+DebugCfg parse_debug_env() {
+  DebugCfg d;
+  const char *e = getenv("APSS_DEBUG");
+  if (!e) return d;
+  std::string str(e);
+  size_t pos = 0;
+  while (pos <= str.size()) {
+    const size_t end = std::min(str.find(',', pos), str.size());
+    const std::string tok = str.substr(pos, end - pos);
+    pos = end + 1;
+    const size_t eq = tok.find('=');
+    const std::string key = tok.substr(0, eq);
+    const int val = eq == std::string::npos ? 1 : atoi(tok.c_str() + eq + 1);
+    if (key == "build_lds") d.build_lds = val != 0;
+    else if (key == "build_atomic") d.build_atomic = val != 0;
+    else if (key == "chunk8") d.chunk8 = val != 0;
+    else if (key == "shard_exact") d.shard_exact = val != 0;
+    else if (key == "diag") d.diag = val != 0;
+    else if (key == "force_general") d.force_general = val != 0;
+    else if (key == "exact_accum") d.exact_accum = val != 0;
+    else if (key == "big_u5") d.big_u5 = val != 0;
+    else if (key == "cx_tile") d.cx_tile = val;
+    else if (key == "window") d.window = val;
+    else if (key == "chunks") d.chunks = val;
+    else if (key == "tiles_per_launch") d.tiles_per_launch = val;
+    else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
+  }
+  return d;
+}
+
 }  // namespace
 
 struct apss_handle {
   apss_config cfg{};
+  DebugCfg dbgcfg;
   int dev = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -96,6 +145,20 @@ struct apss_handle {
   int64_t last_nq = 0;
   DevBuf<unsigned long long> counters, dbg;
   DevBuf<unsigned int> flagword;
+  // dense-head block (apss_head.hpp): the KH most frequent terms live in W instead of the inverted index
+  int32_t head_k = 0;                 // 0: no block
+  int64_t head_eval_rows = 0;         // store size when the head policy last looked at the term distribution
+  bool head_blocked = false;          // a call needed the plain path: no block until the next apss_clear
+  std::vector<int32_t> head_terms;    // the block's terms, in block order
+  DevBuf<int32_t> head_pos, idx_tail; // [dim] term -> position | -1;  store idx with head entries masked (index build input)
+  DevBuf<uint16_t> W, q_W;            // [rows x head_k] bf16 rows of the store / of a staged query batch
+  DevBuf<uint32_t> df;
+  DevBuf<unsigned long long> dedup_tab, head_ctr;
+  DevBuf<int32_t> uq_q, uq_c;         // candidate list after k_pair_dedup
+  DevBuf<float> uq_s;
+  int64_t head_nonempty = 0, last_batch_head_nonempty = 0;
+  int64_t idx_tail_valid = 0;         // entries of idx_tail that are filled in
+  hipEvent_t ev2 = nullptr, ev3 = nullptr;
   // stats
   apss_stats st{};
   size_t bytes_reserved = 0;
@@ -281,7 +344,8 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   APSS_TRY(ensure(h, ix.base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
   APSS_TRY(ensure(h, ix.total, (size_t)n_tiles, 0));
   DevBuf<float> &tmin = ix.coarse ? h->tile_min_c : h->tile_min;
-  if (h->sharded) APSS_TRY(ensure(h, tmin, (size_t)n_tiles, (size_t)tile0));
+  const bool scaled = h->sharded || h->head_k > 0;  // the probe scales its threshold per query and tile (shard rule)
+  if (scaled) APSS_TRY(ensure(h, tmin, (size_t)n_tiles, (size_t)tile0));
   if (ix.h_base.empty()) ix.h_base.push_back(0);
   ix.h_base.resize((size_t)tile0 + 1);  // bases of the tiles that stay
   const int64_t r0 = tile0 * cb;
@@ -289,13 +353,13 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   const int32_t n_ranges = (int32_t)ceil_div(h->cfg.dim, kBuildRange);
   // (one workgroup per (tile, range): with fewer than ~48 of them -- a small batch, a rebuilt tail tile, a 1/8 candidate
   // range -- the row-parallel global-atomic kernels are faster; APSS_BUILD_LDS / APSS_BUILD_ATOMIC force either)
-  const bool lds_build = n_ranges <= kBuildMaxRanges && !getenv("APSS_BUILD_ATOMIC") &&
-                         ((n_tiles - tile0) * n_ranges >= 48 || getenv("APSS_BUILD_LDS"));
+  const bool lds_build = n_ranges <= kBuildMaxRanges && !h->dbgcfg.build_atomic &&
+                         ((n_tiles - tile0) * n_ranges >= 48 || h->dbgcfg.build_lds);
   if (!lds_build)
     HIPCHK(h, hipMemsetAsync(ix.seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
   BuildArgs b{};
   b.rowptr = h->rowptr.p;
-  b.idx = h->idx.p;
+  b.idx = h->head_k ? h->idx_tail.p : h->idx.p;  // dense-head entries are masked out of the inverted index
   b.val = h->val.p;
   b.row0 = r0;
   b.row1 = h->n_rows;
@@ -334,7 +398,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.post_c = ix.post_c.p;
   if (lds_build) hipLaunchKernelGGL(k_tile_scatter_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
   else hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
-  if (h->sharded)
+  if (scaled)
     hipLaunchKernelGGL(k_tile_min_sub, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream,
                        (const float *)h->sub.p, h->n_rows, (int32_t)cb, tmin.p, tile0);
   HIPCHK(h, hipGetLastError());
@@ -357,15 +421,142 @@ int32_t ensure_exact_index(apss_handle *h) {
   return APSS_OK;
 }
 
+// ---- dense-head block (apss_head.hpp) ----
+constexpr int64_t kHeadMinRows = 16384;  // below this a join is over before a GEMM pays for its set-up
+constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse filter (measured, C3)
+constexpr double kHeadDenseRate = 6.0e14;   // flop / s the head contraction sustains (measured, profiles/r02_head_gemm.md)
+
+inline bool head_allowed(const apss_handle *h) {
+  return h->use_coarse && !h->sharded && h->cfg.head_terms >= 0 && h->cfg.theta > 0.0 && !h->head_blocked && h->nonneg;
+}
+
+// W rows, tail ratios and the masked term array for store rows [row0, n_rows)
+int32_t head_pack_store(apss_handle *h, int64_t row0) {
+  const int64_t kh = h->head_k;
+  const int64_t rows_pad = ceil_div(h->n_rows, kHeadQBlock) * kHeadQBlock + kHeadCTile;
+  APSS_TRY(ensure(h, h->W, (size_t)(rows_pad * kh), (size_t)(row0 * kh)));
+  APSS_TRY(ensure(h, h->sub, (size_t)h->n_rows, (size_t)row0));
+  APSS_TRY(ensure(h, h->idx_tail, (size_t)std::max<int64_t>(h->nnz, 1), (size_t)(row0 ? h->idx_tail_valid : 0)));
+  h->idx_tail_valid = h->nnz;
+  APSS_TRY(ensure(h, h->head_ctr, 4));
+  HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
+  if (h->n_rows > row0) {
+    HeadPackArgs a{};
+    a.rowptr = h->rowptr.p;
+    a.idx = h->idx.p;
+    a.val = h->val.p;
+    a.row0 = row0;
+    a.row1 = h->n_rows;
+    a.head_pos = h->head_pos.p;
+    a.kh = (int32_t)kh;
+    a.W = h->W.p;
+    a.w_row0 = row0;
+    a.ratio_t = h->sub.p;
+    a.idx_tail = h->idx_tail.p;
+    a.head_nonempty = reinterpret_cast<unsigned int *>(h->head_ctr.p);
+    hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(h->n_rows - row0, 4)), dim3(256), 0, h->stream, a);
+  }
+  hipLaunchKernelGGL(k_head_zero_rows, dim3(64), dim3(256), 0, h->stream, h->W.p, h->n_rows, rows_pad, (int32_t)kh);
+  HIPCHK(h, hipGetLastError());
+  unsigned int nz = 0;
+  HIPCHK(h, hipMemcpyAsync(&nz, h->head_ctr.p, sizeof(nz), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (row0 == 0) h->head_nonempty = 0;
+  h->head_nonempty += nz;
+  h->last_batch_head_nonempty = nz;
+  return APSS_OK;
+}
+
+// Look at the store's term distribution (sampled document frequencies) and decide which terms, if any, go to the
+// dense block: term t costs df_t^2 posting visits in the inverted index and 2 * N^2 flop as a column of the
+// contraction (half of that for a stored batch: the product is symmetric).  *changed: the block's term set differs.
+int32_t choose_head(apss_handle *h, bool *changed) {
+  *changed = false;
+  const int64_t n = h->n_rows;
+  const int32_t dim = h->cfg.dim;
+  h->head_eval_rows = n;
+  const int64_t stride = std::max<int64_t>(1, n / 65536);
+  const int64_t sampled = ceil_div(n, stride);
+  APSS_TRY(ensure(h, h->df, (size_t)dim));
+  HIPCHK(h, hipMemsetAsync(h->df.p, 0, (size_t)dim * sizeof(uint32_t), h->stream));
+  hipLaunchKernelGGL(k_df_sample, dim3((unsigned)ceil_div(sampled * kWave, 256)), dim3(256), 0, h->stream,
+                     (const int64_t *)h->rowptr.p, (const int32_t *)h->idx.p, n, stride, h->df.p);
+  HIPCHK(h, hipGetLastError());
+  std::vector<uint32_t> df((size_t)dim);
+  HIPCHK(h, hipMemcpyAsync(df.data(), h->df.p, (size_t)dim * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::vector<int32_t> order((size_t)dim);
+  for (int32_t t = 0; t < dim; ++t) order[(size_t)t] = t;
+  const size_t top = (size_t)std::min<int32_t>(dim, 256);
+  std::partial_sort(order.begin(), order.begin() + (ptrdiff_t)top, order.end(),
+                    [&](int32_t x, int32_t y) { return df[(size_t)x] != df[(size_t)y] ? df[(size_t)x] > df[(size_t)y] : x < y; });
+  int32_t k = 0;
+  if (h->cfg.head_terms > 0) {
+    k = h->cfg.head_terms <= 64 ? 64 : (h->cfg.head_terms <= 128 ? 128 : 256);
+  } else if (n >= kHeadMinRows) {
+    double best = 0.0, s2 = 0.0;
+    size_t i = 0;
+    for (int32_t kk : {64, 128, 256}) {
+      for (; i < std::min<size_t>(top, (size_t)kk); ++i) {
+        const double f = (double)df[(size_t)order[i]] / (double)sampled;
+        s2 += f * f;
+      }
+      const double save = s2 / kHeadSparseRate, cost = (double)kk / kHeadDenseRate;  // per N^2 (stored batch: 2 * K * N^2 / 2 flop)
+      if (save >= 1.5 * cost && save - cost > best) {
+        best = save - cost;
+        k = kk;
+      }
+    }
+  }
+  if (k > dim) k = 0;
+  std::vector<int32_t> terms;
+  for (size_t i = 0; i < std::min<size_t>(top, (size_t)k); ++i)
+    if (df[(size_t)order[i]] > 0) terms.push_back(order[i]);
+  if (terms.empty()) k = 0;
+  *changed = k != h->head_k || terms != h->head_terms;
+  if (!*changed) return APSS_OK;
+  h->head_k = k;
+  h->head_terms = terms;
+  if (k) {
+    std::vector<int32_t> pos((size_t)dim, -1);
+    for (size_t i = 0; i < terms.size(); ++i) pos[(size_t)terms[i]] = (int32_t)i;
+    APSS_TRY(ensure(h, h->head_pos, (size_t)dim));
+    HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `pos` goes out of scope
+  }
+  return APSS_OK;
+}
+
 int32_t build_index(apss_handle *h, int64_t row0) {
   h->st.build_ms = 0;
+  if (head_allowed(h)) {
+    if (h->n_rows >= std::max<int64_t>(h->cfg.head_terms > 0 ? 1 : kHeadMinRows, 2 * h->head_eval_rows)) {
+      bool changed = false;
+      APSS_TRY(choose_head(h, &changed));
+      if (changed) {  // every tile's posting lists change with the term set: rebuild from the first row
+        row0 = 0;
+        h->cx.n_tiles = 0;
+        h->ex_built_rows = 0;
+      }
+    }
+    if (h->head_k) {
+      h->cx.cb = std::min(h->cx.cb, 32768);  // the sparse half runs the 512-thread shard-rule kernel
+      APSS_TRY(head_pack_store(h, row0));
+    }
+  } else if (h->head_k) {  // e.g. a negative weight arrived: back to the plain index
+    h->head_k = 0;
+    h->head_terms.clear();
+    row0 = 0;
+    h->cx.n_tiles = 0;
+    h->ex_built_rows = 0;
+  }
   if (h->use_coarse) {
-    if (h->cx.n_tiles == 0 && h->cfg.tile_rows == 0 && !getenv("APSS_CX_TILE") && h->n_rows > 0) {
+    if (h->cx.n_tiles == 0 && h->cfg.tile_rows == 0 && !h->dbgcfg.cx_tile && h->n_rows > 0) {
       // a round's cost is mostly fixed, so what matters is how many postings a (tile, term) segment holds:
       // rows_per_tile * nnz_per_row / dim.  Below ~16 at 32768 rows (C5 shape: 6.5) the 65536-row tile with one
       // 1024-thread workgroup per CU wins (C5 shape at N=2M: 647 vs 790 ms); at C3 (33) two workgroups per CU win.
       const double seg32 = 32768.0 * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;
-      h->cx.cb = seg32 < 16.0 && !h->sharded ? 65536 : 32768;  // (the 1024-thread kernel has no shard variant)
+      h->cx.cb = seg32 < 16.0 && !h->sharded && !h->head_k ? 65536 : 32768;  // (the 1024-thread kernel has no shard variant)
     }
     APSS_TRY(build_tiles(h, h->cx, row0));
     h->st.build_ms += h->cx.build_ms;
@@ -387,10 +578,133 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
   return APSS_OK;
 }
 
+// ---- the filter kernel's instantiations: (threads, register-window steps, shard rule, postings per chunk, virtual
+// rows, signed weights).  One table, one lookup: a combination that is not listed is an error, never another kernel.
+#define APSS_CX_VARIANTS(X)            \
+  X(512, 5, false, 16, false, false)   \
+  X(512, 4, false, 16, false, false)   \
+  X(512, 3, false, 16, false, false)   \
+  X(512, 2, false, 16, false, false)   \
+  X(512, 5, true, 16, false, false)    \
+  X(512, 4, true, 16, false, false)    \
+  X(512, 3, true, 16, false, false)    \
+  X(512, 2, true, 16, false, false)    \
+  X(512, 4, false, 8, false, false)    \
+  X(512, 5, false, 16, true, false)    \
+  X(512, 5, false, 16, false, true)    \
+  X(512, 5, false, 16, true, true)     \
+  X(1024, 5, false, 16, false, false)  \
+  X(1024, 3, false, 16, false, false)  \
+  X(1024, 5, false, 16, true, false)   \
+  X(1024, 3, false, 16, true, false)   \
+  X(1024, 5, false, 16, false, true)   \
+  X(1024, 3, false, 16, false, true)
+
+struct CxVariant {
+  int block, u;
+  bool shard;
+  int chunk;
+  bool vrows, sgn;
+};
+
+bool cx_variant_exists(const CxVariant &v) {
+#define X(B, U, SH, CH, VR, SG) \
+  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG) return true;
+  APSS_CX_VARIANTS(X)
+#undef X
+  return false;
+}
+
+int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
+  const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
+#define X(B, U, SH, CH, VR, SG)                                                                              \
+  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG) {          \
+    hipLaunchKernelGGL((k_probe_coarse<B, U, (B <= 512 ? 128 : 256), (B <= 512 ? 512 : 1024), SH, CH, VR, SG>), grid, dim3(B), 0, \
+                       h->stream, a);                                                                        \
+    HIPCHK(h, hipGetLastError());                                                                            \
+    return APSS_OK;                                                                                          \
+  }
+  APSS_CX_VARIANTS(X)
+#undef X
+  return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
+}
+
+// ---- dense-head filter of one query batch (apss_head.hpp): appends its candidates to the sparse filter's list ----
+int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_base, const uint16_t *Wq, int64_t wq_rows,
+                 float thr) {
+  const int kh = h->head_k;
+  if (nq <= 2 * kGemvQ) {
+    HeadGemvArgs g{};
+    g.Wq = Wq;
+    g.Wc = h->W.p;
+    g.n_rows = h->n_rows;
+    g.q_slot_base = q_slot_base;
+    g.nq = (int32_t)nq;
+    g.kh = kh;
+    g.q_ext = a.q_ext;
+    g.c_ext = h->ext.p;
+    g.thr = thr;
+    g.res_q = a.res_q;
+    g.res_c = a.res_c;
+    g.res_s = a.res_s;
+    g.res_cap = a.res_cap;
+    g.counters = a.counters;
+    g.head_pairs = h->head_ctr.p + 1;
+    const int64_t blocks = std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div(h->n_rows, 32)));
+    hipLaunchKernelGGL(k_head_gemv, dim3((unsigned)blocks), dim3(256), 0, h->stream, g);
+    HIPCHK(h, hipGetLastError());
+    h->st.head_flops = 2.0 * kh * (double)nq * (double)h->n_rows;
+    return APSS_OK;
+  }
+  HeadGemmArgs g{};
+  g.Wq = Wq;
+  g.Wc = h->W.p;
+  g.wq_rows = wq_rows;
+  g.n_rows = h->n_rows;
+  g.q_slot_base = q_slot_base;
+  g.nq = (int32_t)nq;
+  const int64_t qs0 = q_slot_base >= 0 ? q_slot_base : 0;
+  g.qblock0 = qs0 / kHeadQBlock * kHeadQBlock;
+  g.n_qblocks = (int32_t)(ceil_div(qs0 + nq, kHeadQBlock) - qs0 / kHeadQBlock);
+  g.n_ctiles = (int32_t)ceil_div(h->n_rows, kHeadCTile);
+  // candidate panels: enough workgroups to fill the chip several times over, a multiple of 8 (= XCDs) so that every
+  // workgroup of an XCD streams panels of one residue class, and long enough to amortise the A-fragment load
+  int64_t panels = 8;
+  while (panels * g.n_qblocks < 2048 && g.n_ctiles / (2 * panels) >= 32) panels *= 2;
+  panels = std::max<int64_t>(1, std::min<int64_t>(panels, g.n_ctiles));
+  g.n_panels = (int32_t)panels;
+  g.tiles_per_panel = (int32_t)ceil_div(g.n_ctiles, panels);
+  g.q_ext = a.q_ext;
+  g.c_ext = h->ext.p;
+  g.thr = thr;
+  g.res_q = a.res_q;
+  g.res_c = a.res_c;
+  g.res_s = a.res_s;
+  g.res_cap = a.res_cap;
+  g.counters = a.counters;
+  g.head_pairs = h->head_ctr.p + 1;
+  const dim3 grid((unsigned)((int64_t)g.n_qblocks * g.n_panels));
+  if (kh == 64) hipLaunchKernelGGL(k_head_gemm<64>, grid, dim3(512), 0, h->stream, g);
+  else if (kh == 128) hipLaunchKernelGGL(k_head_gemm<128>, grid, dim3(512), 0, h->stream, g);
+  else hipLaunchKernelGGL(k_head_gemm<256>, grid, dim3(512), 0, h->stream, g);
+  HIPCHK(h, hipGetLastError());
+  // multiplied elements: every (query block, candidate tile) the grid does not skip, at MFMA granularity
+  double tiles = 0;
+  for (int64_t b = 0; b < g.n_qblocks; ++b) {
+    const int64_t hi = q_slot_base >= 0 ? std::min<int64_t>(g.n_ctiles, (g.qblock0 + (b + 1) * kHeadQBlock) / kHeadCTile) : g.n_ctiles;
+    tiles += (double)hi;
+  }
+  h->st.head_flops = 2.0 * kh * tiles * (double)kHeadCTile * (double)kHeadQBlock;
+  return APSS_OK;
+}
+
 // ---- probe the whole index with a query batch resident on the device ----
+// q_head: rows of the batch in the dense-head block (null when the handle has none): the store's W for a stored batch,
+// the staged q_W otherwise.
 int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t *q_idx, const float *q_val,
               const int64_t *q_ext, const float *q_sub, int64_t q_slot_base, int64_t q_max_nnz, float q_max_norm2,
               int64_t q_nnz_end, int64_t *n_results) {
+  const DebugCfg &dbg = h->dbgcfg;
   h->res_q_ext = q_ext;
   h->last_q_rowptr = q_rowptr;
   h->last_q_idx = q_idx;
@@ -400,6 +714,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.posting_visits = h->st.candidate_pairs = h->st.result_pairs = 0;
   h->st.probe_ms = 0;
   h->st.probe_launches = 0;
+  h->st.head_pairs = h->st.head_survivors = 0;
+  h->st.head_ms = h->st.head_flops = 0;
+  h->st.head_terms = h->head_k ? (int64_t)h->head_terms.size() : 0;
   if (n_results) *n_results = 0;
   APSS_TRY(ensure(h, h->counters, kCtrCount));
   h->st.filter_survivors = 0;
@@ -417,7 +734,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // products is at most |q| * |c| <= the product of the largest row norms
   const double bound = std::sqrt((double)q_max_norm2) * std::sqrt((double)h->store_max_norm2) * 1.0001 + 1e-6;
   const double fx_scale = bound < 3.9 ? 1073741824.0 : (bound < 15.6 ? 268435456.0 : 0.0);
-  const bool forced_general = (h->cfg.flags & APSS_FLAG_FORCE_GENERAL) || getenv("APSS_FORCE_GENERAL");
+  const bool forced_general = (h->cfg.flags & APSS_FLAG_FORCE_GENERAL) || dbg.force_general;
 
   // ---- path 1: two-pass join (coarse filter + exact rescoring) ----
   // accumulator units per 1.0: a 16-bit sum holds S * |q||c| (fp16 weights: + 2^-11) plus one unit per shared term
@@ -431,33 +748,44 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const double cx_theta = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
   const bool cx_selective = cx_scale >= 16384.0 || cx_theta >= 4.0 * cx_shared;
   const bool cx_fp16_ok = std::sqrt((double)h->store_max_norm2) < 60000.0;  // a weight never exceeds its row's norm
-  // (shard mode scales the threshold down per query and tile: the kernel clamps it at 1, which only admits more)
-  // weights of either sign with theta > 0 go through the filter too (it then sums positive products only); term shards
-  // (and long queries over 65536-row tiles) have no such instantiation and keep the general kernel
-  const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !h->sharded &&
-                         (h->cx.cb <= 32768 || q_max_nnz <= 512) &&
-                         !getenv("APSS_CX_CHUNK8") && !getenv("APSS_CX_U3") && !getenv("APSS_CX_U4");
+  // the shard rule (term-range shards, and the sparse half of a handle with a dense-head block) scales the threshold
+  // down per query and tile: the kernel clamps it at 1, which only admits more
+  const bool hybrid_wanted = h->head_k > 0;
+  const float head_thr = (float)(theta - 0.0080 * bound - 1e-5);
+  // weights of either sign with theta > 0 go through the filter too (it then sums positive products only); shard-rule
+  // launches (and long queries over 65536-row tiles) have no such instantiation and keep the general kernel
+  const bool shard_rule = h->sharded || hybrid_wanted;
+  const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !shard_rule &&
+                         (h->cx.cb <= 32768 || q_max_nnz <= 512) && !dbg.chunk8 && !dbg.window;
   const bool coarse_path = h->use_coarse && (mode == 0 || cx_signed) && cx_selective && cx_fp16_ok && !forced_general && nq < (1LL << 30) &&
-                           !(h->sharded && h->cx.cb > 32768) &&
-                           (q_max_nnz <= 512 || !h->sharded) &&
-                           !getenv("APSS_EXACT_ACCUM") && cx_scale > 0 && cx_theta < 65000.0 && (h->sharded || cx_theta - 2 >= 1.0) &&
+                           !(shard_rule && h->cx.cb > 32768) &&
+                           (q_max_nnz <= 512 || !shard_rule) &&
+                           !dbg.exact_accum && cx_scale > 0 && cx_theta < 65000.0 && (shard_rule || cx_theta - 2 >= 1.0) &&
                            std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
+  if (hybrid_wanted && !(coarse_path && mode == 0 && head_thr >= 0.5 * theta)) {
+    // this call cannot take the hybrid path (signed or very long queries, norms out of range ...): the dense block's
+    // terms go back into the inverted index, for good, and the call runs as on a handle without a block
+    h->head_blocked = true;
+    APSS_TRY(build_index(h, 0));
+    return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_sub, q_slot_base, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
+  }
+  const bool hybrid = hybrid_wanted;
 
   ProbeArgs a{};
   a.seg_stride = (int64_t)h->cfg.dim;
   a.ext_id = h->ext.p;
-  a.c_scale = h->sharded ? h->sub.p : nullptr;
+  a.c_scale = shard_rule ? h->sub.p : nullptr;
   a.n_rows = h->n_rows;
   a.q_rowptr = q_rowptr;
   a.q_idx = q_idx;
   a.q_val = q_val;
   a.q_ext = q_ext;
-  a.q_scale = h->sharded ? q_sub : nullptr;
+  a.q_scale = shard_rule ? q_sub : nullptr;
   a.nq = (int32_t)nq;
   a.q_nnz_end = q_nnz_end;
   // ~2 workgroups per CU per tile in flight at once, tiles swept one after another (tile-major grid) so the
   // chip works on one tile's postings at a time and they stay in L2 / Infinity Cache
-  const int64_t want_chunks = getenv("APSS_CHUNKS") ? atoi(getenv("APSS_CHUNKS")) : 1024;  // (env: tuning hook)
+  const int64_t want_chunks = dbg.chunks > 0 ? dbg.chunks : 1024;
   a.q_chunk = (int32_t)std::max<int64_t>(1, ceil_div(nq, want_chunks));
   a.n_chunks = (int32_t)ceil_div(nq, a.q_chunk);
   a.q_slot_base = q_slot_base;
@@ -472,7 +800,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.post = h->ex.post.p;
   a.post_c = h->cx.post_c.p;
   a.tile_post_base = ix.base.p;
-  a.tile_scale = h->sharded ? (coarse_path ? h->tile_min_c.p : h->tile_min.p) : nullptr;
+  a.tile_scale = shard_rule ? (coarse_path ? h->tile_min_c.p : h->tile_min.p) : nullptr;
   a.cb = ix.cb;
   a.n_tiles = (int32_t)ix.n_tiles;
 
@@ -492,13 +820,31 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.fx_scale = (float)scale_used;
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::max(1.0, std::ceil(theta * scale_used)));
   a.theta_fxi = (int32_t)std::max(-2147483647.0, std::min(2147483647.0, std::ceil(theta * scale_used)));
-  const bool cx_big = h->cx.cb > 32768;  // experiment: one 1024-thread workgroup per CU over a 65536-row tile
-  // the sparse regime's wave holds few, short segments: a 3-step register window (24 chunks per wave) wastes fewer idle
-  // steps than the 5-step one as long as a wave's expected chunks stay well inside it (C5 shape: 458 vs 604 ms at N=2M)
-  const double cx_seg = (double)h->cx.cb * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;
-  const double cx_wave_chunks = ((double)q_nnz_end / (double)nq / 16.0) * std::max(1.0, cx_seg / 16.0 + 0.5);
-  const bool cx_big_u3 = cx_big && cx_wave_chunks <= 17.0 && !getenv("APSS_CX_BIG_U5");
-  const bool cx8 = getenv("APSS_CX_CHUNK8") != nullptr;  // experiment: 8-posting chunks, 4 steps
+
+  // ---- which instantiation of the filter kernel: the register window (U steps of 8 chunks per wave) is sized for the
+  // chunks a wave expects per round; a round's cost grows with U whether or not its slots hold postings, so thin rounds
+  // (term shards: 1/T of a query's terms; sparse regimes: short segments) take a short window
+  CxVariant cxv{};
+  if (coarse_path) {
+    cxv.block = h->cx.cb > 32768 ? 1024 : 512;
+    cxv.shard = shard_rule;
+    cxv.chunk = dbg.chunk8 ? 8 : 16;
+    cxv.vrows = q_max_nnz > 512;
+    cxv.sgn = cx_signed;
+    const double nw = cxv.block / kWave;
+    const double seg = (double)h->cx.cb * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;  // postings per (tile, term)
+    double q_terms = (double)q_nnz_end / (double)nq;
+    if (shard_rule) q_terms += 2.0 * std::sqrt(q_terms);  // a shard holds a binomial share of each query's terms
+    const double wave_chunks = std::ceil(q_terms / nw - 1e-9) * std::max(1.0, seg / 16.0 + 0.5);
+    int u = (int)std::ceil(wave_chunks * 1.05 / 8.0);
+    if (cxv.block == 1024) u = (q_terms / nw) * std::max(1.0, seg / 16.0 + 0.5) <= 17.0 && !dbg.big_u5 ? 3 : 5;
+    else u = std::max(2, std::min(5, u));
+    if (cxv.vrows || cxv.sgn) u = cxv.block == 1024 ? u : 5;
+    if (dbg.chunk8) u = 4;
+    if (dbg.window && cxv.block == 512 && !cxv.vrows && !cxv.sgn) u = dbg.window;
+    cxv.u = u;
+    if (!cx_variant_exists(cxv)) return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
+  }
   const int vrow_part = 512;
   // (the filter kernels keep their LDS in static arrays: no dynamic allocation)
   const size_t lds = coarse_path ? 0
@@ -552,7 +898,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   if (total_tiles > 0) {
     const double per_tile = (double)q_nnz_end * ((double)h->nnz / (double)total_tiles / (double)h->cfg.dim) + 1.0;
     tiles_per_launch = (int64_t)std::min<double>((double)total_tiles, std::max(1.0, std::floor(2e11 / per_tile)));
-    if (getenv("APSS_TILES_PER_LAUNCH")) tiles_per_launch = std::max(1, atoi(getenv("APSS_TILES_PER_LAUNCH")));  // test hook
+    if (dbg.tiles_per_launch > 0) tiles_per_launch = dbg.tiles_per_launch;
     tiles_per_launch = std::min<int64_t>(tiles_per_launch, std::max<int64_t>(1, 2000000000LL / std::max(1, a.n_chunks)));
   }
   if (h->res_q.cap < (size_t)std::min<int64_t>(2 * nq, 1LL << 28)) {
@@ -562,6 +908,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     APSS_TRY(ensure(h, h->res_c, cap0, 0, true));
     APSS_TRY(ensure(h, h->res_s, cap0, 0, true));
   }
+  if (hybrid) APSS_TRY(ensure(h, h->head_ctr, 4));
   for (int attempt = 0; attempt < 3; ++attempt) {
     a.dbg = nullptr;
     a.res_q = h->res_q.p;
@@ -572,87 +919,49 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     int64_t n_launches = 0;
     for (int64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_launch, ++n_launches) {
-    a.tile0 = (int32_t)t0;
-    a.n_tiles = (int32_t)std::min<int64_t>(tiles_per_launch, total_tiles - t0);
-    if (coarse_path) {
-      if (a.vq_first && cx_big) {
-        if (cx_big_u3) {
-          auto kern = k_probe_coarse<1024, 3, 256, 1024, false, 16, true>;
-          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
-        } else {
-          auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, true>;
-          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
-        }
-      } else if (a.vq_first && cx_signed && !cx_big) {
-        auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, true, true>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
-      } else if (cx_signed && !cx_big) {
-        auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, false, true>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
-      } else if (a.vq_first) {
-        auto kern = k_probe_coarse<512, 5, 128, 512, false, 16, true>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
-      } else if (cx_big && cx_signed) {
-        if (cx_big_u3) {
-          auto kern = k_probe_coarse<1024, 3, 256, 1024, false, 16, false, true>;
-          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
-        } else {
-          auto kern = k_probe_coarse<1024, 5, 256, 1024, false, 16, false, true>;
-          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
-        }
-      } else if (cx_big) {
-        if (cx_big_u3) {
-          auto kern = k_probe_coarse<1024, 3, 256, 1024, false>;
-          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
-        } else {
-          auto kern = k_probe_coarse<1024, 5, 256, 1024, false>;
-          hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(1024), lds, h->stream, a);
-        }
-      } else if (getenv("APSS_CX_U4") && !h->sharded) {  // experiment hook: a 32-chunk window
-        auto kern = k_probe_coarse<512, 4, 128, 512, false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
-      } else if (getenv("APSS_CX_U3") && !h->sharded) {  // test hook: a 24-chunk window, most rounds overflow it
-        auto kern = k_probe_coarse<512, 3, 128, 512, false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
-      } else if (cx8 && !h->sharded) {
-        auto kern = k_probe_coarse<512, 4, 128, 512, false, 8>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
-      } else if (h->sharded) {
-        auto kern = k_probe_coarse<512, 5, 128, 512, true>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
+      a.tile0 = (int32_t)t0;
+      a.n_tiles = (int32_t)std::min<int64_t>(tiles_per_launch, total_tiles - t0);
+      if (coarse_path) {
+        APSS_TRY(launch_cx(h, cxv, a));
+      } else if (wave_path && dbg.diag) {
+        // diagnostic build: in-kernel cycle stamps per round segment (shares only; never a benchmark number)
+        APSS_TRY(ensure(h, h->dbg, 8));
+        HIPCHK(h, hipMemsetAsync(h->dbg.p, 0, 8 * sizeof(unsigned long long), h->stream));
+        a.dbg = h->dbg.p;
+        APSS_TRY(launch_wave(true));
+        unsigned long long d[8];
+        HIPCHK(h, hipMemcpyAsync(d, h->dbg.p, sizeof(d), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        unsigned long long tot = 0;
+        for (int k = 0; k < 7; ++k) tot += d[k];
+        fprintf(stderr, "[apss diag] stage+flatten %.1f%% | atomics %.1f%% | longs/rest %.1f%% | barrier G %.1f%% | survivors %.1f%% | "
+                        "re-zero %.1f%% | barrier U %.1f%% | cycles/round/wave %.0f\n",
+                100.0 * d[0] / tot, 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot,
+                100.0 * d[5] / tot, 100.0 * d[6] / tot, (double)tot / ((double)a.n_tiles * a.nq * (wave_block / kWave)));
+      } else if (wave_path) {
+        APSS_TRY(launch_wave(false));
+      } else if (gen_fx) {
+        if (mode == 0) APSS_TRY((launch_probe<0, true>(h, a, lds)));
+        else if (mode == 1) APSS_TRY((launch_probe<1, true>(h, a, lds)));
+        else APSS_TRY((launch_probe<2, true>(h, a, lds)));
       } else {
-        auto kern = k_probe_coarse<512, 5, 128, 512, false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(512), lds, h->stream, a);
+        if (mode == 0) APSS_TRY((launch_probe<0, false>(h, a, lds)));
+        else if (mode == 1) APSS_TRY((launch_probe<1, false>(h, a, lds)));
+        else APSS_TRY((launch_probe<2, false>(h, a, lds)));
       }
-      HIPCHK(h, hipGetLastError());
-    } else if (wave_path && getenv("APSS_DIAG")) {
-      // diagnostic build: in-kernel cycle stamps per round segment (shares only; never a benchmark number)
-      APSS_TRY(ensure(h, h->dbg, 8));
-      HIPCHK(h, hipMemsetAsync(h->dbg.p, 0, 8 * sizeof(unsigned long long), h->stream));
-      a.dbg = h->dbg.p;
-      APSS_TRY(launch_wave(true));
-      unsigned long long d[8];
-      HIPCHK(h, hipMemcpyAsync(d, h->dbg.p, sizeof(d), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      unsigned long long tot = 0;
-      for (int k = 0; k < 7; ++k) tot += d[k];
-      fprintf(stderr, "[apss diag] stage+flatten %.1f%% | atomics %.1f%% | longs/rest %.1f%% | barrier G %.1f%% | survivors %.1f%% | "
-                      "re-zero %.1f%% | barrier U %.1f%% | cycles/round/wave %.0f\n",
-              100.0 * d[0] / tot, 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot,
-              100.0 * d[5] / tot, 100.0 * d[6] / tot, (double)tot / ((double)a.n_tiles * a.nq * (wave_block / kWave)));
-    } else if (wave_path) {
-      APSS_TRY(launch_wave(false));
-    } else if (gen_fx) {
-      if (mode == 0) APSS_TRY((launch_probe<0, true>(h, a, lds)));
-      else if (mode == 1) APSS_TRY((launch_probe<1, true>(h, a, lds)));
-      else APSS_TRY((launch_probe<2, true>(h, a, lds)));
-    } else {
-      if (mode == 0) APSS_TRY((launch_probe<0, false>(h, a, lds)));
-      else if (mode == 1) APSS_TRY((launch_probe<1, false>(h, a, lds)));
-      else APSS_TRY((launch_probe<2, false>(h, a, lds)));
-    }
     }  // tile groups
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    unsigned long long sparse_results = 0, head_c[4] = {0, 0, 0, 0};
+    if (hybrid) {
+      // the dense half: same candidate list, same counter
+      HIPCHK(h, hipMemcpyAsync(&sparse_results, h->counters.p + kCtrResults, sizeof(sparse_results), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
+      HIPCHK(h, hipEventRecord(h->ev2, h->stream));
+      const bool stored = q_slot_base >= 0;
+      APSS_TRY(run_head(h, a, nq, q_slot_base, stored ? h->W.p : h->q_W.p, stored ? (int64_t)(h->W.cap / h->head_k) : nq, head_thr));
+      HIPCHK(h, hipEventRecord(h->ev3, h->stream));
+      HIPCHK(h, hipMemcpyAsync(head_c, h->head_ctr.p, sizeof(head_c), hipMemcpyDeviceToHost, h->stream));
+    }
     unsigned long long c[kCtrCount];
     HIPCHK(h, hipMemcpyAsync(c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -665,6 +974,17 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     // the speed paths count a stored query's touch of its own slot; it is not a (q, c != q) pair
     if ((wave_path || coarse_path) && q_slot_base >= 0)
       h->st.candidate_pairs -= (q_slot_base == 0 && nq == h->n_rows) ? h->store_nonempty : h->last_batch_nonempty;
+    if (hybrid) {
+      HIPCHK(h, hipEventElapsedTime(&ms, h->ev2, h->ev3));
+      h->st.head_ms += ms;
+      // positive elements of the contraction, minus a stored query's product with itself
+      int64_t self = 0;
+      if (q_slot_base >= 0) self = (q_slot_base == 0 && nq == h->n_rows) ? h->head_nonempty : h->last_batch_head_nonempty;
+      h->st.head_pairs = (int64_t)head_c[1] - self;
+      h->st.head_survivors = (int64_t)(c[kCtrResults] - sparse_results);
+      // a pair sharing head AND tail terms is scored by both filters; the distinct count lies between max and sum
+      h->st.candidate_pairs = std::max(h->st.candidate_pairs, h->st.head_pairs);
+    }
     h->st.result_pairs = (int64_t)c[kCtrResults];
     if (c[kCtrResults] > a.res_cap) {
       // the result list overflowed: grow to what the run asked for and repeat the (idempotent) probe
@@ -679,10 +999,32 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     h->out_c = h->res_c.p;
     h->out_s = h->res_s.p;
     if (coarse_path && !h->sharded) {
-      // exact pass: re-score what the filter let through from the fp32 store and prune at theta
-      const int64_t n_cand = h->n_res;
+      // exact pass: re-score what the filter(s) let through from the fp32 store and prune at theta
+      int64_t n_cand = h->n_res;
       h->st.filter_survivors = n_cand;
       h->n_res = 0;
+      const int32_t *cand_q = h->res_q.p, *cand_c = h->res_c.p;
+      if (hybrid && n_cand > 0) {
+        // a pair that passed both filters is in the list twice
+        uint64_t tab = 1024;
+        while (tab < (uint64_t)n_cand * 2) tab <<= 1;
+        APSS_TRY(ensure(h, h->dedup_tab, (size_t)tab, 0, true));
+        APSS_TRY(ensure(h, h->uq_q, (size_t)n_cand, 0, true));
+        APSS_TRY(ensure(h, h->uq_c, (size_t)n_cand, 0, true));
+        APSS_TRY(ensure(h, h->uq_s, (size_t)n_cand, 0, true));
+        HIPCHK(h, hipMemsetAsync(h->dedup_tab.p, 0xff, (size_t)tab * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(k_pair_dedup, dim3((unsigned)ceil_div(n_cand, 256)), dim3(256), 0, h->stream,
+                           (const int32_t *)h->res_q.p, (const int32_t *)h->res_c.p, (const float *)h->res_s.p, n_cand,
+                           h->dedup_tab.p, tab - 1, h->uq_q.p, h->uq_c.p, h->uq_s.p, h->counters.p);
+        HIPCHK(h, hipGetLastError());
+        unsigned long long nu = 0;
+        HIPCHK(h, hipMemcpyAsync(&nu, h->counters.p, sizeof(nu), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        n_cand = (int64_t)nu;
+        cand_q = h->uq_q.p;
+        cand_c = h->uq_c.p;
+      }
       if (n_cand > 0) {
         APSS_TRY(ensure(h, h->fin_q, (size_t)n_cand, 0, true));
         APSS_TRY(ensure(h, h->fin_c, (size_t)n_cand, 0, true));
@@ -690,8 +1032,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
         HIPCHK(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
         RescoreArgs r{};
         r.n_pairs = n_cand;
-        r.q_row = h->res_q.p;
-        r.c_slot = h->res_c.p;
+        r.q_row = cand_q;
+        r.c_slot = cand_c;
         r.q_rowptr = q_rowptr;
         r.q_idx = q_idx;
         r.q_val = q_val;
@@ -769,6 +1111,14 @@ int32_t insert_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d
                         const float *d_val, const int64_t *d_ext, int64_t *first_new_row) {
   *first_new_row = h->n_rows;
   if (n == 0) return APSS_OK;
+  // the results and the query batch of the last call may point into store arrays that this insert reallocates:
+  // they are gone (apss_fetch_results / apss_partial_scores_dev answer APSS_E_STATE until the next query-type call)
+  h->n_res = -1;
+  h->res_q_ext = nullptr;
+  h->last_q_rowptr = nullptr;
+  h->last_q_idx = nullptr;
+  h->last_q_val = nullptr;
+  h->last_nq = 0;
   if (h->n_rows + n > 0x7fffffffLL) return fail(h, APSS_E_INVALID, "more than 2^31 - 1 vectors in one handle");
   int64_t kept_rows = 0, kept_nnz = 0;
   APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, true, &kept_rows, &kept_nnz));
@@ -783,6 +1133,26 @@ int32_t query_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_
                        const float *d_val, const int64_t *d_ext, int64_t *n_results) {
   int64_t kept_rows = 0, kept_nnz = 0;
   APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, false, &kept_rows, &kept_nnz));
+  if (h->head_k && kept_rows > 0) {
+    // the batch's rows of the dense-head block and its tail ratios (the store's were packed when it was indexed)
+    APSS_TRY(ensure(h, h->q_W, (size_t)(kept_rows * h->head_k)));
+    APSS_TRY(ensure(h, h->q_sub, (size_t)kept_rows));
+    HeadPackArgs a{};
+    a.rowptr = h->q_rowptr.p;
+    a.idx = h->q_idx.p;
+    a.val = h->q_val.p;
+    a.row0 = 0;
+    a.row1 = kept_rows;
+    a.head_pos = h->head_pos.p;
+    a.kh = h->head_k;
+    a.W = h->q_W.p;
+    a.w_row0 = 0;
+    a.ratio_t = h->q_sub.p;
+    a.idx_tail = nullptr;
+    a.head_nonempty = nullptr;
+    hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(kept_rows, 4)), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+  }
   return probe(h, kept_rows, h->q_rowptr.p, h->q_idx.p, h->q_val.p, h->q_ext.p, h->q_sub.p, -1, h->q_max_nnz, h->q_max_norm2,
                kept_nnz, n_results);
 }
@@ -809,6 +1179,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   apss_handle *h = new (std::nothrow) apss_handle();
   if (!h) return APSS_E_NOMEM;
   h->cfg = *cfg;
+  h->dbgcfg = parse_debug_env();
   if (h->cfg.term_hi == 0 && h->cfg.term_lo == 0) h->cfg.term_hi = cfg->dim;
   if (h->cfg.term_lo < 0 || h->cfg.term_hi > cfg->dim || h->cfg.term_lo >= h->cfg.term_hi) {
     g_create_error = "bad term range";
@@ -819,12 +1190,12 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   // term-range shards use the coarse filter too (measured T=2: 130 ms vs 195 ms per shard with the single-pass kernel);
   // their survivors are the shard's candidates, scored exactly in phase 2.  APSS_SHARD_EXACT=1: single-pass kernel.
   h->use_coarse = !(cfg->flags & (APSS_FLAG_EXACT_ACCUM | APSS_FLAG_FORCE_GENERAL | APSS_FLAG_FORCE_SCAN)) &&
-                  (!h->sharded || !getenv("APSS_SHARD_EXACT"));
+                  (!h->sharded || !h->dbgcfg.shard_exact);
   h->cb = cfg->tile_rows ? cfg->tile_rows : 16384;
   h->ex.cb = h->cb;
   h->ex.align = kSegAlign;
   h->cx.cb = std::min(2 * h->cb, 32768);
-  if (getenv("APSS_CX_TILE")) h->cx.cb = atoi(getenv("APSS_CX_TILE"));  // experiment hook (multiple of 64, <= 65536)
+  if (h->dbgcfg.cx_tile) h->cx.cb = h->dbgcfg.cx_tile;  // experiment hook (multiple of 64, <= 65536)
   h->cx.align = kSegAlignC;
   h->cx.coarse = true;
   if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {
@@ -847,7 +1218,8 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
     return APSS_E_DEVICE;
   }
   if ((e = hipSetDevice(h->dev)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault)) != hipSuccess ||
-      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
+      (e = hipEventCreate(&h->ev2)) != hipSuccess || (e = hipEventCreate(&h->ev3)) != hipSuccess) {
     g_create_error = std::string("HIP init failed: ") + hipGetErrorString(e);
     delete h;
     return APSS_E_DEVICE;
@@ -887,8 +1259,12 @@ void apss_destroy(apss_handle *h) {
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
   release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val); release(h->in_val64); release(h->vq_first); release(h->vrow_q); release(h->vrow_ptr); release(h->vrow_np); release(h->vrow_first);
   release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword); release(h->dbg);
+  release(h->head_pos); release(h->idx_tail); release(h->W); release(h->q_W); release(h->df); release(h->dedup_tab);
+  release(h->head_ctr); release(h->uq_q); release(h->uq_c); release(h->uq_s);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->ev3) (void)hipEventDestroy(h->ev3);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -1019,7 +1395,7 @@ int32_t apss_insert_and_query_dev(apss_handle *h, int64_t n, int64_t nnz, const 
   APSS_TRY(insert_dev_impl(h, n, nnz, d_rowptr, d_indices, d_values, d_ext_ids, &first));
   const int64_t nq = h->n_rows - first;
   // the batch is now rows [first, n_rows) of the store: query it in place (rowptr offsets are absolute)
-  return probe(h, nq, h->rowptr.p + first, h->idx.p, h->val.p, h->ext.p + first, h->sharded ? h->sub.p + first : nullptr,
+  return probe(h, nq, h->rowptr.p + first, h->idx.p, h->val.p, h->ext.p + first, (h->sharded || h->head_k) ? h->sub.p + first : nullptr,
                first, h->store_max_nnz, h->store_max_norm2, h->nnz, n_results);
 }
 
@@ -1032,10 +1408,20 @@ int32_t apss_clear(apss_handle *h) {
   for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { s->n_tiles = 0; s->post_used = 0; s->h_base.clear(); }
   h->ex_built_rows = 0;
   h->n_res = -1;
+  h->res_q_ext = nullptr;
+  h->last_q_rowptr = nullptr;
+  h->last_q_idx = nullptr;
+  h->last_q_val = nullptr;
+  h->last_nq = 0;
   h->nonneg = true;
   h->store_max_nnz = 0;
   h->store_max_norm2 = 0.f;
   h->store_nonempty = 0;
+  h->head_k = 0;
+  h->head_terms.clear();
+  h->head_eval_rows = 0;
+  h->head_blocked = false;
+  h->head_nonempty = 0;
   return APSS_OK;
 }
 
@@ -1050,12 +1436,24 @@ int32_t apss_results_dev(apss_handle *h, const int32_t **d_q_row, const int32_t 
   return APSS_OK;
 }
 
+int32_t apss_results_copy_dev(apss_handle *h, int64_t offset, int64_t count, int32_t *d_q_row, int32_t *d_c_slot,
+                              float *d_score) {
+  APSS_TRY(enter(h));
+  if (h->n_res < 0) return fail(h, APSS_E_STATE, "no query has run on this handle since the last insert");
+  if (offset < 0 || count < 0 || offset + count > h->n_res) return fail(h, APSS_E_INVALID, "copy range out of bounds");
+  if (count == 0) return APSS_OK;
+  if (d_q_row) HIPCHK(h, hipMemcpyAsync(d_q_row, h->out_q + offset, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  if (d_c_slot) HIPCHK(h, hipMemcpyAsync(d_c_slot, h->out_c + offset, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  if (d_score) HIPCHK(h, hipMemcpyAsync(d_score, h->out_s + offset, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  return APSS_OK;
+}
+
 int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *d_q_row, const int32_t *d_c_slot,
                                 float *d_out_partial) {
   APSS_TRY(enter(h));
   if (n_pairs < 0) return fail(h, APSS_E_INVALID, "negative pair count");
   if (n_pairs == 0) return APSS_OK;
-  if (!h->last_q_rowptr) return fail(h, APSS_E_STATE, "no query batch on this handle");
+  if (!h->last_q_rowptr) return fail(h, APSS_E_STATE, "no query batch on this handle since the last insert");
   if (!d_q_row || !d_c_slot || !d_out_partial) return fail(h, APSS_E_INVALID, "null device pointer");
   PartialArgs a{};
   a.n_pairs = n_pairs;

@@ -66,7 +66,7 @@ struct IngestArgs {
   int64_t *row_keep;  // [n] 0/1
   int64_t *row_cnt;   // [n] kept entries (0 for dropped rows)
   float *row_inv;     // [n] 1/norm (1 when not normalising)
-  float *row_sub;     // [n] L2 norm of the kept entries (the shard's sub-norm)
+  float *row_sub;     // [n] |x_g| / |x|: norm of the entries kept for this term range over the row's full norm
   unsigned int *flags_out;  // [0]: bit0 malformed indices, bit1 non-finite value, bit2 negative value kept; [1]: max kept row length; [2]: bits of the max squared row norm; [3]: non-empty kept rows
 };
 
@@ -93,11 +93,13 @@ __global__ void k_ingest_count(IngestArgs a) {
     b = e = 0;
   }
   const bool normalise = (a.flags & 4u) != 0;  // without it one pass over the row does everything
-  float sumsq = 0.f, sum = 0.f, sub = 0.f;
+  float sumsq = 0.f, sum = 0.f, sub = 0.f, full = 0.f;
   int cnt = 0;
   auto account = [&](const float v, const int32_t t) {
     sum += v;  // EPA:89 with max-weight 1.0
-    const bool keep = (!(a.flags & 1u) || v > a.index_threshold) && t >= a.term_lo && t < a.term_hi;  // WWA:192
+    const bool keep_v = !(a.flags & 1u) || v > a.index_threshold;  // WWA:192: the pruned vector is what is scored
+    if (keep_v) full += v * v;
+    const bool keep = keep_v && t >= a.term_lo && t < a.term_hi;
     if (keep) {
       cnt++;
       sub += v * v;
@@ -120,6 +122,7 @@ __global__ void k_ingest_count(IngestArgs a) {
   }
   for (int o = G / 2; o; o >>= 1) {
     sum += __shfl_xor(sum, o, G);
+    full += __shfl_xor(full, o, G);
     sub += __shfl_xor(sub, o, G);
     cnt += __shfl_xor(cnt, o, G);
     bad |= __shfl_xor(bad, o, G);
@@ -129,7 +132,9 @@ __global__ void k_ingest_count(IngestArgs a) {
     a.row_keep[row] = admit ? 1 : 0;
     a.row_cnt[row] = admit ? cnt : 0;
     a.row_inv[row] = inv;
-    a.row_sub[row] = sqrtf(sub);
+    // the shard rule's scale: |x_g| / |x| (x_g = the row restricted to this handle's term range), rounded up a hair so
+    // that it only ever lowers a threshold; 1 on a handle that holds the whole term space
+    a.row_sub[row] = full > 0.f ? fminf(1.0f, sqrtf(sub / full) * 1.000001f) : 0.f;
     if (bad) atomicOr(&sh[0], bad);
     if (admit) {
       atomicMax(&sh[1], (unsigned)cnt);         // longest kept row: picks the probe kernel
@@ -247,7 +252,7 @@ __device__ __forceinline__ uint32_t pack_coarse(uint32_t slot, float w) {
 
 struct BuildArgs {
   const int64_t *rowptr;
-  const int32_t *idx;
+  const int32_t *idx;             // term of every entry; an entry held by the dense-head block has kNoTerm here
   const float *val;
   int64_t row0, row1;
   int32_t cb;
@@ -270,7 +275,10 @@ __global__ void k_tile_hist(BuildArgs a) {
   if (row >= a.row1) return;
   uint2 *sg = a.tile_seg + (row / a.cb) * a.seg_stride;
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
-  for (int64_t k = b + lane; k < e; k += kWave) atomicAdd(&sg[a.idx[k]].y, 1u);
+  for (int64_t k = b + lane; k < e; k += kWave) {
+    const int32_t t = a.idx[k];
+    if ((uint32_t)t < (uint32_t)a.dim) atomicAdd(&sg[t].y, 1u);  // (an entry of the dense-head block carries no term here)
+  }
 }
 
 // one workgroup per tile: exclusive scan of the aligned lengths; tile_total[tile] = postings incl. padding
@@ -311,6 +319,7 @@ __global__ void k_tile_scatter(BuildArgs a) {
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
   for (int64_t k = b + lane; k < e; k += kWave) {
     const int32_t t = a.idx[k];
+    if ((uint32_t)t >= (uint32_t)a.dim) continue;  // dense-head entry: not in the inverted index
     // one 64-bit returning atomic on {start, cursor}: bumps the cursor (high word) and brings the start along
     const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(&sg[t]), 1ull << 32);
     const uint32_t pos = (uint32_t)old + (uint32_t)(old >> 32);

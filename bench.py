@@ -4,12 +4,17 @@
 A step is one pass of the hot path over one batch: the IndexData handler on the whole synthetic batch
 (IndexingWorkerActor.scala:123-137 = build the index from the batch, then query the batch against it: a
 single-batch self-join), inputs already resident in HBM.  Workload = BASELINE.json configs[2] "Synthetic N=1M,
-dim=100k, nnz=100, cosine theta=0.8" (the configuration the metric is quoted on); --workload picks another.
+dim=100k, nnz=100, cosine theta=0.8" (the configuration the metric is quoted on); --workload picks another
+(c2 | c3 | c3z | c3z1 | c5s | c5 | c5z: apss/synth.py).
 
     python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (term-range shards, RCCL)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).
+N > 1 times BOTH layouts of SURVEY.md 8(e), K steps each, same barriers: the contract's (term-range shards across the N
+GPUs, RCCL all-gather of candidate lists + all-reduce of partial scores: WriteWorkerActor.scala:164-183 turned into
+range shards) is `value`; candidate-range shards (no data-path collective) are the `candidate_range_layout` row.
+
+Prints ONE JSON line (rank 0).  A rank that stalls ends the process with exit code 3 (watchdog), never 0.
 """
 import argparse
 import json
@@ -27,7 +32,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # ... 6.29 TB/s measured float4 copy
-BYTES_PER_VISIT = 8            # one posting = int32 slot + fp32 weight
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # ... dense bf16 MFMA peak (no sparsity)
+BYTES_PER_VISIT = 8            # one posting = int32 slot + fp32 weight (the ACCOUNTING unit)
+METRIC = "scored candidate pairs/sec + achieved HBM GB/s, N=1M d=100k nnz=100, 1/2/4/8 GPU"
 
 
 def parse():
@@ -35,17 +42,40 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", help="c2 | c3 | c3z | c5s | c5 (BASELINE.json configs; c3 is the metric's)")
+    ap.add_argument("--workload", default="c3", help="c2 | c3 | c3z | c3z1 | c5s | c5 | c5z (c3 is the metric's)")
     ap.add_argument("--n", type=int, default=None, help="override the number of vectors (debug)")
     ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--head-terms", type=int, default=0, help="dense-head block: 0 auto, -1 never, 64 | 128 | 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid: term-range shards per candidate range (default 1)")
+    ap.add_argument("--no-exact-row", action="store_true", help="skip the fp32-accumulate sibling measurement")
+    ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid of the headline layout (default: all ranks)")
     ap.add_argument("--solo", default=None, help="T,D,i,j: time shard (term i of T, rows j of D) alone on this GPU (projection)")
-    ap.add_argument("--no-term-row", action="store_true", help="skip the term-sharded comparison row of multi-GPU runs")
-    ap.add_argument("--term-row-deadline", type=float, default=120.0, help="seconds allowed for the term-sharded comparison row")
+    ap.add_argument("--no-comparison-row", action="store_true", help="skip the candidate-range layout of multi-GPU runs")
+    ap.add_argument("--deadline", type=float, default=900.0, help="seconds before the watchdog ends a stalled run (exit 3)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real run) | gloo (rehearsal: all ranks share GPU 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the baseline sample")
     return ap.parse_args()
+
+
+class Watchdog:
+    """A stalled collective or kernel must not look like success: past the deadline the process prints what it was
+    doing and leaves with exit code 3 (os._exit: a rank stuck inside a collective cannot unwind)."""
+
+    def __init__(self, seconds, rank):
+        self.phase, self.rank = "start", rank
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def fire(self):
+        sys.stderr.write("[bench] rank %d stalled in phase '%s': exit 3\n" % (self.rank, self.phase))
+        if self.rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "error": "stalled in phase '%s'" % self.phase}), flush=True)
+        sys.stderr.flush()
+        os._exit(3)
+
+    def done(self):
+        self.t.cancel()
 
 
 def cpu_baseline(cfg, rp, idx, val, budget_s):
@@ -63,11 +93,226 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
     opt = oracle.selfjoin_sample(1, cfg["dim"], cfg["theta"], rp, idx, val, 0, min(n, sample * 20), cores)
     return {
         "value": r["cand_pairs"] / r["seconds"], "unit": "scored candidate pairs/s", "cores": cores, "kind": "port",
-        "sample": "all %d vectors indexed, first %d queries timed (%.1f s, %d threads); reference algorithm: posting "
-                  "lists + per-candidate HashMap dot in double" % (n, sample, r["seconds"], cores),
+        "sample": "all %d vectors indexed, first %d queries timed (%.1f s, %d threads: queries split by range, every "
+                  "pair scored once -- more generous than the reference's term-modulo workers, which re-score a pair "
+                  "on every worker sharing a dim, EntryProxyActor.scala:41-46); reference algorithm: posting lists + "
+                  "per-candidate HashMap dot in double" % (n, sample, r["seconds"], cores),
         "optimised_cpu_value": opt["cand_pairs"] / opt["seconds"],
         "optimised_cpu_note": "fairness bracket: CSC + dense double accumulator, %d threads" % cores,
     }
+
+
+def profile_quote(workload, n_override, tile_rows, alg_bytes):
+    """HBM-side bytes and SQ counters of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the
+    committed summary of the same command (profiles/collect_r02.sh -> profiles/r02_probe_traffic.json) is quoted when
+    the workload matches byte for byte."""
+    path = os.path.join(ROOT, "profiles", "r02_probe_traffic.json")
+    if n_override or tile_rows or not os.path.exists(path):
+        return None
+    tj = json.load(open(path))
+    ent = tj.get(workload)
+    if not ent or ent.get("algorithmic_bytes_per_launch") != alg_bytes:
+        return None
+    return ent
+
+
+def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
+    import torch
+    from apss import _lib
+    from apss.engine import ApssIndex
+    n = cfg["n"]
+    d_rp, d_idx, d_val = d_arrays
+    d_ids = torch.arange(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()  # the library runs on its own stream
+
+    def run(flags, steps, warmup):
+        ix = ApssIndex(cfg["dim"], cfg["theta"], device=local_rank, tile_rows=a.tile_rows, capacity_rows=n,
+                       capacity_nnz=d_idx.numel(), flags=flags, head_terms=a.head_terms)
+
+        def step():
+            ix.clear()
+            return ix.insert_and_query_dev(d_ids, d_rp, d_idx, d_val)
+
+        for _ in range(warmup):
+            step()
+        sync()
+        per = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            n_pairs = step()
+            per.append(ix.stats())
+        sync()
+        dt = time.perf_counter() - t0
+        ix.close()
+        return dt, n_pairs, per
+
+    wd.phase = "timed steps"
+    dt, n_pairs, per = run(0, a.steps, a.warmup)
+    st = per[-1]
+    mean = lambda k: float(np.mean([s[k] for s in per]))  # noqa: E731
+    sec_per_step = dt / a.steps
+    visits, cands, launches = st["posting_visits"], st["candidate_pairs"], max(1, st["probe_launches"])
+    probe_s, head_s = mean("probe_ms") * 1e-3, mean("head_ms") * 1e-3
+    alg_bytes = BYTES_PER_VISIT * visits
+    hybrid = st["head_terms"] > 0
+    filter_kernel = "k_probe_coarse (16-bit LDS accumulators, 4-B postings) + k_rescore" if st["filter_survivors"] or not visits \
+        else "k_probe_wave / k_probe"
+    out = {
+        "value": cands / sec_per_step,
+        "ms_per_step": sec_per_step * 1e3,
+        "posting_visits_per_step": visits,
+        "candidate_pairs_per_step": cands,
+        "result_pairs_per_step": int(n_pairs),
+        "posting_visits_per_s": visits / sec_per_step,
+        "algorithmic_GBps_whole_step": alg_bytes / sec_per_step / 1e9,
+        "build_ms": mean("build_ms"),
+        "probe_kernel_ms": mean("probe_ms"),
+        "rescore_ms": mean("rescore_ms"),
+        "filter_survivors": st["filter_survivors"],
+    }
+    sparse_frac = (alg_bytes / launches / (probe_s / launches) / 1e9) / HBM_PEAK_GBS if probe_s > 0 else None
+    quote = profile_quote(a.workload, a.n, a.tile_rows, alg_bytes)
+    sparse_roof = {
+        # what the counters show (profiles/r02_sq_counters.txt): the filter kernel's busiest unit is the LDS pipeline
+        # (returning 16-bit atomics + clears), not HBM; `frac` stays the SURVEY 8(d) accounting figure (8 B per visit)
+        "bound": "lds", "kernel": filter_kernel,
+        "achieved": alg_bytes / probe_s / 1e9 if probe_s > 0 else None,
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sparse_frac,
+        "frac_note": "ALGORITHMIC: 8 B x posting visits per launch / HIP-event kernel time / 8 TB/s (SURVEY.md 8d accounting "
+                     "unit; the filter reads 4-B postings, so this figure may exceed what the memory system moved)",
+        "launches": launches,
+        "traffic": None, "measured_frac": None, "measured_frac_of_copy_peak": None,
+    }
+    if quote:
+        traffic = quote["traffic_bytes_per_launch_corrected"]
+        sparse_roof.update({
+            "traffic": traffic,
+            "measured_frac": traffic / (probe_s / launches) / 1e9 / HBM_PEAK_GBS,
+            "measured_frac_of_copy_peak": traffic / (probe_s / launches) / 1e9 / HBM_COPY_GBS,
+            "traffic_note": "bytes per launch at the L2 <-> fabric boundary, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate "
+                            "rocprofv3 --pmc passes of this command (profiles/r02_probe_traffic.json); gfx950 tallies 128-B read "
+                            "requests at 64 B; Infinity-Cache hits are included, HBM itself sees each posting once per step",
+            "lds_issue_frac": quote.get("lds_issue_frac"), "valu_busy_frac": quote.get("valu_busy_frac"),
+        })
+    if hybrid:
+        flops = st["head_flops"]
+        out.update({"head_terms": st["head_terms"], "head_pairs_per_step": st["head_pairs"], "head_kernel_ms": head_s * 1e3,
+                    "head_survivors": st["head_survivors"],
+                    "candidate_pairs_note": "max(pairs sharing a tail term, pairs sharing a head term): a lower bound of "
+                                            "the distinct pairs scored (a pair sharing both kinds is scored by both filters)"})
+        head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d> (v_mfma_f32_32x32x16_bf16)" % st["head_terms"],
+                     "achieved": flops / head_s / 1e12 if head_s > 0 else None, "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flops / head_s / 1e12 / MFMA_BF16_PEAK_TFLOPS if head_s > 0 else None,
+                     "traffic": None,
+                     "flops_note": "2 x KH x (512-slot query blocks x 64-row candidate tiles the grid multiplies; the upper "
+                                   "triangle of a stored batch is skipped) per launch / HIP-event kernel time"}
+        if head_s >= probe_s:
+            out["roofline"], out["roofline_sparse_filter"] = head_roof, sparse_roof
+        else:
+            out["roofline"], out["roofline_dense_head"] = sparse_roof, head_roof
+    else:
+        out["roofline"] = sparse_roof
+    # the fp32-everywhere sibling: single-pass kernel with exact u32 / fp32 accumulators, 8-B postings (what `frac`
+    # means literally); measured in the same run so that the line carries both
+    if not a.no_exact_row and not hybrid:
+        wd.phase = "exact-accumulate sibling"
+        dt2, n2, per2 = run(_lib.FLAG_EXACT_ACCUM, max(1, min(2, a.steps)), 1)
+        s2 = per2[-1]
+        ps = float(np.mean([s["probe_ms"] for s in per2])) * 1e-3
+        l2 = max(1, s2["probe_launches"])
+        ex = {"kernel": "k_probe_wave (8-B postings, exact u32 fixed-point accumulators, single pass)",
+              "probe_kernel_ms": ps * 1e3, "ms_per_step": dt2 / len(per2) * 1e3, "result_pairs": int(n2),
+              "frac": BYTES_PER_VISIT * s2["posting_visits"] / ps / 1e9 / HBM_PEAK_GBS if ps > 0 else None,
+              "measured_frac": None, "launches": l2}
+        if quote and quote.get("exact_traffic_bytes_per_launch_corrected"):
+            ex["traffic"] = quote["exact_traffic_bytes_per_launch_corrected"]
+            ex["measured_frac"] = ex["traffic"] / (ps / l2) / 1e9 / HBM_PEAK_GBS
+        out["roofline"]["exact_accum"] = ex
+        assert int(n2) == int(n_pairs), "the two probe paths disagree on the result set size"
+    return out, "1 GPU", {}
+
+
+def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync, wd):
+    import torch
+    import torch.distributed as dist
+    from apss.dist import ShardedJoin
+    from apss.engine import ApssIndex
+    n = cfg["n"]
+    # distinct scored candidate pairs of the workload (a pair sharing terms in k shards is touched by k shards):
+    # counted once, untimed, by a plain single-GPU join on rank 0
+    wd.phase = "distinct pair count (rank 0, untimed)"
+    distinct = torch.zeros(1, dtype=torch.float64, device=comm_dev)
+    if rank == 0:
+        ix0 = ApssIndex(cfg["dim"], cfg["theta"], device=local_rank, tile_rows=a.tile_rows, head_terms=a.head_terms)
+        ix0.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ix0.insert_and_query_dev(torch.arange(n, dtype=torch.int64, device=dev), torch.from_numpy(rp).to(dev),
+                                 torch.from_numpy(idx).to(dev), torch.from_numpy(val.astype(np.float32)).to(dev))
+        distinct[0] = float(ix0.stats()["candidate_pairs"])
+        ix0.close()
+        del ix0
+        torch.cuda.empty_cache()
+    dist.all_reduce(distinct)
+    cands = int(distinct.item())
+
+    def timed(T, label):
+        wd.phase = label
+        sj = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev, term_shards=T)
+        sj.load(rp, idx, val)
+        probe_ms, build_ms = [], []
+        for _ in range(a.warmup):
+            sj.step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            n_pairs = sj.step()
+            probe_ms.append(sj.last["probe_ms"])
+            build_ms.append(sj.last["build_ms"])
+        sync()
+        t = torch.tensor([time.perf_counter() - t0, float(np.mean(probe_ms)), float(np.mean(build_ms))], dtype=torch.float64,
+                         device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank
+        dt, pm, bm = (float(x) for x in t.tolist())
+        sec = dt / a.steps
+        row = {
+            "grid": "%d term-range shards x %d candidate ranges" % (sj.T, sj.D),
+            "value": cands / sec, "ms_per_step": sec * 1e3, "result_pairs_per_step": int(n_pairs),
+            "probe_kernel_ms_slowest_shard": pm, "build_ms_slowest_shard": bm,
+            "posting_visits_per_step": sj.last["posting_visits"], "shard_touched_pairs_sum": sj.last["candidate_pairs"],
+            "exchange": sj.last.get("exchange"),
+            "collectives": ("per step: all-gather of candidate lists + all-reduce(SUM) of per-candidate partial scores inside "
+                            "each term group, all-reduce of counters over all ranks" if sj.T > 1 else
+                            "per step: all-reduce of counters only (result sets of different candidate ranges are disjoint)"),
+        }
+        visits = sj.last["posting_visits"]
+        row["roofline"] = {"bound": "lds", "kernel": "k_probe_coarse<SHARD>" if sj.T > 1 else "k_probe_coarse",
+                           "achieved": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 if pm > 0 else None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s (per GPU: slowest shard's kernel, 1/N of the job's 8-B posting visits)",
+                           "frac": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS if pm > 0 else None,
+                           "traffic": None}
+        del sj.engine
+        del sj
+        torch.cuda.empty_cache()
+        return row
+
+    T = a.term_shards or world
+    head = timed(T, "headline layout: %d term-range shards" % T)
+    extra = {"layout": "term-range shards (the contract: BASELINE.json configs[3], SURVEY.md 8e)", "backend": a.backend,
+             "exchange": head["exchange"], "shard_touched_pairs_sum": head["shard_touched_pairs_sum"],
+             "collectives": head["collectives"]}
+    if not a.no_comparison_row and T != 1:
+        comp = timed(1, "comparison layout: candidate ranges")
+        extra["candidate_range_layout"] = comp
+        assert comp["result_pairs_per_step"] == head["result_pairs_per_step"], "the two layouts disagree on the result set size"
+    out = {
+        "value": head["value"], "ms_per_step": head["ms_per_step"],
+        "posting_visits_per_step": head["posting_visits_per_step"], "candidate_pairs_per_step": cands,
+        "result_pairs_per_step": head["result_pairs_per_step"],
+        "posting_visits_per_s": head["posting_visits_per_step"] / (head["ms_per_step"] * 1e-3),
+        "algorithmic_GBps_whole_step": BYTES_PER_VISIT * head["posting_visits_per_step"] / (head["ms_per_step"] * 1e-3) / 1e9,
+        "build_ms": head["build_ms_slowest_shard"], "probe_kernel_ms": head["probe_kernel_ms_slowest_shard"],
+        "roofline": head["roofline"],
+    }
+    return out, head["grid"] + "; " + head["collectives"], extra
 
 
 def main():
@@ -75,30 +320,39 @@ def main():
     import torch
     import torch.distributed as dist
     from apss import synth
-    from apss.engine import ApssIndex
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    wd = Watchdog(a.deadline, rank)
     if a.backend == "gloo":
         local_rank = 0  # rehearsal on a one-GPU box: every rank drives GPU 0, collectives on CPU tensors
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm_dev = torch.device("cpu") if a.backend == "gloo" else dev
     if world > 1:
+        wd.phase = "process group"
         if a.backend == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    wd.phase = "data generation"
     cfg = dict(synth.CONFIGS[a.workload])
     if a.n:
         cfg["n"] = a.n
     t0 = time.time()
-    rp, idx, val = synth.make_vectors(cfg["n"], cfg["dim"], cfg["nnz"], cfg["zipf_s"], cfg["seed"])
+    d_arrays = None
+    if cfg.get("gen") == "zipf_dev":
+        # drawn on the device (the host loop needs minutes per million Zipf rows); the host copy feeds the CPU baseline
+        d_rp, d_idx2, d_val2 = synth.make_vectors_zipf_dev(cfg["n"], cfg["dim"], cfg["nnz"], cfg["zipf_s"], cfg["seed"], dev)
+        d_arrays = (d_rp, d_idx2.reshape(-1).contiguous(), d_val2.reshape(-1).contiguous())
+        rp, idx = d_rp.cpu().numpy(), d_arrays[1].cpu().numpy()
+        val = d_arrays[2].double().cpu().numpy()
+    else:
+        rp, idx, val = synth.make_vectors(cfg["n"], cfg["dim"], cfg["nnz"], cfg["zipf_s"], cfg["seed"])
     gen_s = time.time() - t0
     n = cfg["n"]
 
@@ -110,6 +364,7 @@ def main():
 
     if a.solo:
         from apss.dist import HipShardEngine, term_ranges
+        wd.phase = "solo shard"
         T, D, ti, dj = (int(x) for x in a.solo.split(","))
         tr = term_ranges(np.bincount(idx, minlength=cfg["dim"]), T)[ti]
         eng = HipShardEngine(cfg["dim"], cfg["theta"], tr, dev, a.tile_rows)
@@ -124,180 +379,49 @@ def main():
         dt = (time.perf_counter() - t0) / a.steps
         print(json.dumps({"solo_shard": a.solo, "ms_per_step": dt * 1e3, "probe_kernel_ms": eng.stats["probe_ms"],
                           "build_ms": eng.stats["build_ms"], "posting_visits": eng.stats["posting_visits"],
-                          "candidates": int(n_c)}))
+                          "candidates": int(n_c),
+                          "algorithmic_frac": BYTES_PER_VISIT * eng.stats["posting_visits"] / (eng.stats["probe_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}))
+        wd.done()
         return
+
     if world == 1:
-        d_rp = torch.from_numpy(rp).to(dev)
-        d_idx = torch.from_numpy(idx).to(dev)
-        d_val = torch.from_numpy(val.astype(np.float32)).to(dev)
-        d_ids = torch.arange(n, dtype=torch.int64, device=dev)
-        torch.cuda.synchronize()  # the library runs on its own stream
-        ix = ApssIndex(cfg["dim"], cfg["theta"], device=local_rank, tile_rows=a.tile_rows, capacity_rows=n,
-                       capacity_nnz=idx.size)
-
-        def step():
-            ix.clear()
-            return ix.insert_and_query_dev(d_ids, d_rp, d_idx, d_val)
-
-        probe_ms, build_ms = [], []
-        for _ in range(a.warmup):
-            step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            n_pairs = step()
-            st = ix.stats()
-            probe_ms.append(st["probe_ms"])
-            build_ms.append(st["build_ms"])
-        sync()
-        dt = time.perf_counter() - t0
-        visits, cands = st["posting_visits"], st["candidate_pairs"]
-        launches = st["probe_launches"]
-        parallelism = "1 GPU"
-        extra = {}
-        hung = False
+        if d_arrays is None:
+            d_arrays = (torch.from_numpy(rp).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(val.astype(np.float32)).to(dev))
+        body, parallelism, extra = single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd)
     else:
-        from apss.dist import ShardedJoin
-        # distinct scored candidate pairs of the workload (a pair sharing terms in k shards is touched by k shards):
-        # counted once, untimed, by a plain single-GPU join on rank 0
-        distinct = torch.zeros(1, dtype=torch.float64, device=comm_dev)
-        if rank == 0:
-            ix0 = ApssIndex(cfg["dim"], cfg["theta"], device=local_rank, tile_rows=a.tile_rows)
-            ix0.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-            ix0.insert_and_query_dev(torch.arange(n, dtype=torch.int64, device=dev), torch.from_numpy(rp).to(dev),
-                                     torch.from_numpy(idx).to(dev), torch.from_numpy(val.astype(np.float32)).to(dev))
-            distinct[0] = float(ix0.stats()["candidate_pairs"])
-            ix0.close()
-            del ix0
-            torch.cuda.empty_cache()
-        dist.all_reduce(distinct)
-        sj = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev,
-                         term_shards=a.term_shards)
-        sj.load(rp, idx, val)
-        probe_ms, build_ms = [], []
-        for _ in range(a.warmup):
-            sj.step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            n_pairs = sj.step()
-            probe_ms.append(sj.last["probe_ms"])
-            build_ms.append(sj.last["build_ms"])
-        sync()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        pm = torch.tensor([float(np.mean(probe_ms))], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(pm, op=dist.ReduceOp.MAX)
-        probe_ms = [float(pm.item())]  # slowest shard's probe kernel
-        visits, cands, launches = sj.last["posting_visits"], int(distinct.item()), world
-        # comparison row, measured in the same run: the term-sharded layout of BASELINE.json configs[3] (T = 2 term
-        # ranges per candidate range, candidate all-gather + RCCL all-reduce of partial scores); not part of `value`
-        term_row = None
-        hung = False
-        if world % 2 == 0 and (a.term_shards or 1) == 1 and not a.no_term_row:
-            del sj.engine
-            torch.cuda.empty_cache()
+        d_arrays = None
+        torch.cuda.empty_cache()
+        body, parallelism, extra = multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync, wd)
 
-            def term_sharded_step():
-                torch.cuda.set_device(dev)
-                sj2 = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev,
-                                  term_shards=2)
-                sj2.load(rp, idx, val)
-                sj2.step()
-                sync()
-                t1 = time.perf_counter()
-                n2 = sj2.step()
-                sync()
-                t2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=comm_dev)
-                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-                return {"grid": "2 term ranges x %d candidate ranges" % (world // 2), "ms_per_step": float(t2.item()) * 1e3,
-                        "result_pairs": int(n2), "exchange": sj2.last["exchange"]}
-
-            # the comparison row must never take the benchmark down: it runs under a deadline on every rank; a rank
-            # that raises or stalls (its peers then wait in a collective) reports the fact and the main line still prints
-            box = {}
-
-            def guarded():
-                try:
-                    box["row"] = term_sharded_step()
-                except Exception as e:
-                    box["row"] = {"error": repr(e)[:200]}
-
-            th = threading.Thread(target=guarded, daemon=True)
-            th.start()
-            th.join(a.term_row_deadline)
-            hung = th.is_alive()
-            term_row = {"error": "no answer within %g s" % a.term_row_deadline} if hung else box.get("row")
-        parallelism = ("%d candidate ranges, no data-path collective (term-sharded layouts: --term-shards)" % sj.D
-                       if sj.T == 1 else "%d term-range shards x %d candidate ranges; per term group: candidate "
-                       "all-gather + RCCL all-reduce of partial scores" % (sj.T, sj.D))
-        extra = {"exchange": sj.last.get("exchange"), "shard_touched_pairs_sum": sj.last["candidate_pairs"],
-                 "backend": a.backend, "term_sharded_comparison": term_row}
-
-    if rank != 0:
-        if world > 1 and hung:
-            os._exit(0)  # a stalled comparison step still holds a collective: do not wait for it
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    sec_per_step = dt / a.steps
-    kern_s = float(np.mean(probe_ms)) * 1e-3
-    alg_bytes = BYTES_PER_VISIT * visits
-    out = {
-        "metric": "scored candidate pairs/sec + achieved HBM GB/s, N=1M d=100k nnz=100, 1/2/4/8 GPU",
-        "value": cands / sec_per_step,
-        "unit": "scored candidate pairs/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": sec_per_step * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
-        "vs_baseline": None,
-        "dtype": "u16+f32",  # 16-bit fixed-point filter sums, fp32 exact rescoring of the survivors
-        "data": "synthetic",
-        "config": {"workload": "%s: N=%d dim=%d nnz=%d %s theta=%g, single-batch self-join (build + probe)" % (
-            a.workload, n, cfg["dim"], cfg["nnz"], "Zipf(%g)" % cfg["zipf_s"] if cfg["zipf_s"] else "uniform",
-            cfg["theta"]), "parallelism": parallelism, "tile_rows": a.tile_rows or 16384},
-        "posting_visits_per_step": visits,
-        "candidate_pairs_per_step": cands,
-        "result_pairs_per_step": int(n_pairs),
-        "posting_visits_per_s": visits / sec_per_step,
-        "algorithmic_GBps_whole_step": alg_bytes / sec_per_step / 1e9,
-        "build_ms": float(np.mean(build_ms)),
-        "probe_kernel_ms": float(np.mean(probe_ms)),
-        "datagen_s": gen_s,
-        "roofline": {
-            "bound": "hbm", "kernel": "k_probe",
-            "achieved": alg_bytes / launches / kern_s / 1e9 if kern_s > 0 else None,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (alg_bytes / launches / kern_s / 1e9) / HBM_PEAK_GBS if kern_s > 0 else None,
-            "frac_of_measured_copy_peak": (alg_bytes / launches / kern_s / 1e9) / HBM_COPY_GBS if kern_s > 0 else None,
-            "traffic": None,
-            "note": "achieved = 8 B x posting visits per launch / HIP-event kernel time on the launch stream",
-        },
-    }
-    # HBM-side bytes per probe launch: rocprofv3 PMC passes cannot run inside this process; the committed summary of
-    # the same command (profiles/collect_r01.sh -> profiles/r01_probe_traffic.json) is quoted when the workload matches
-    tpath = os.path.join(ROOT, "profiles", "r01_probe_traffic.json")
-    if world == 1 and a.workload == "c3" and not a.n and not a.tile_rows and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("algorithmic_bytes_per_launch") == alg_bytes:
-            out["roofline"]["traffic"] = tj["traffic_bytes_per_launch_corrected"]
-            out["roofline"]["traffic_note"] = ("bytes per launch, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 "
-                                               "--pmc passes of this command (profiles/r01_probe_traffic.json); gfx950 tallies "
-                                               "128-B read requests at 64 B; Infinity-Cache hits are included")
-    out.update(extra)
-    if not a.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds)
-    elif not a.no_cpu_baseline:
-        out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
-    if world > 1 and hung:
-        os._exit(0)
+    if rank == 0:
+        out = {
+            "metric": METRIC,
+            "value": body.pop("value"),
+            "unit": "scored candidate pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": body.pop("ms_per_step"),
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "u16+f32" if not body.get("head_terms") else "u16+bf16+f32",  # 16-bit fixed-point filter sums (+ bf16 MFMA head filter), fp32 exact rescoring
+            "data": "synthetic",
+            "config": {"workload": "%s: N=%d dim=%d nnz=%d %s theta=%g, single-batch self-join (build + probe)" % (
+                a.workload, n, cfg["dim"], cfg["nnz"], "Zipf(%g)" % cfg["zipf_s"] if cfg["zipf_s"] else "uniform",
+                cfg["theta"]), "parallelism": parallelism,
+                "tile_rows": a.tile_rows or "library default (coarse index: 32768 rows per tile, 65536 in the sparse regime)"},
+            "datagen_s": gen_s,
+        }
+        out.update(body)
+        out.update(extra)
+        if not a.no_cpu_baseline:
+            wd.phase = "cpu baseline"
+            out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 6.0))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        wd.phase = "shutdown"
+        dist.barrier()
         dist.destroy_process_group()
+    wd.done()
 
 
 if __name__ == "__main__":

@@ -11,8 +11,9 @@
  *
  * Conventions: plain pointers and sizes only; every function returns an int32 status (0 = ok, < 0 = error,
  * text via apss_last_error); nothing throws or calls back across the boundary; inputs are caller-owned and
- * consumed before return; results stay in the handle until the next query-type call and are copied out
- * with apss_fetch_results (two-call pattern: ask for the count, then fetch).
+ * consumed before return; results stay in the handle until the next query-type call, insert or clear (after an
+ * insert or clear the result calls answer APSS_E_STATE) and are copied out with apss_fetch_results (two-call
+ * pattern: ask for the count, then fetch).
  * Threading mirrors the actor model: at most one thread inside a given handle at a time, different handles
  * may be used concurrently; the library sets the device on every entry and owns one HIP stream per handle.
  *
@@ -64,7 +65,9 @@ typedef struct apss_config {
   int32_t term_hi;         /*   (0, 0) or (0, dim) = the whole term space (single GPU) */
   int32_t tile_rows;       /* candidate tile = rows whose fp32 accumulators share one workgroup's LDS;
                               0 = default (16384: two workgroups share a CU's 160 KB of LDS); a multiple of 64, <= 32768 */
-  int32_t reserved0;
+  int32_t head_terms;      /* dense-head block: 0 = the library decides from the term distribution, -1 = never,
+                              64 | 128 | 256 = always that many of the most frequent terms.  Terms in the block are scored
+                              by a bf16 MFMA contraction instead of their posting lists; results are the same set */
   int64_t capacity_rows;   /* hints for the initial HBM reservation (0 = grow on demand) */
   int64_t capacity_nnz;
 } apss_config;
@@ -74,7 +77,9 @@ typedef struct apss_stats {
   int64_t nnz;              /* postings in the index */
   int64_t tiles;            /* candidate tiles */
   int64_t posting_visits;   /* (query, term, posting) FMAs of the last query-type call */
-  int64_t candidate_pairs;  /* distinct (q, c != q) pairs scored by the last query-type call */
+  int64_t candidate_pairs;  /* distinct (q, c != q) pairs scored by the last query-type call.  With a dense-head block:
+                               max(pairs sharing a tail term, pairs sharing a head term), a LOWER bound of the distinct
+                               count (a pair sharing both kinds is scored by both filters, counted once here) */
   int64_t result_pairs;     /* pairs >= theta of the last query-type call */
   double probe_ms;          /* device time of the last call's probe kernel(s), HIP events */
   double build_ms;          /* device time of the last insert's index build, HIP events */
@@ -82,6 +87,11 @@ typedef struct apss_stats {
   int64_t hbm_bytes;        /* device bytes currently reserved by the handle */
   int64_t filter_survivors; /* two-pass join: pairs the coarse filter passed on to exact rescoring (0: single pass) */
   double rescore_ms;        /* two-pass join: device time of the exact rescoring kernel */
+  int64_t head_terms;       /* terms held in the dense-head block at the last call (0: none) */
+  int64_t head_pairs;       /* (q, c != q) pairs sharing a head term, scored by the dense contraction of the last call */
+  int64_t head_survivors;   /* pairs the dense filter passed on to exact rescoring */
+  double head_ms;           /* device time of the dense-head kernel, HIP events */
+  double head_flops;        /* 2 * KH * (query slots x candidate rows actually multiplied) of the last call */
 } apss_stats;
 
 /* ---- lifetime (actor construction / stop, IWA:21-39) ---- */
@@ -136,11 +146,18 @@ int32_t apss_clear(apss_handle *h);
  * float score; valid until the next query-type call */
 int32_t apss_results_dev(apss_handle *h, const int32_t **d_q_row, const int32_t **d_c_slot,
                          const float **d_score, int64_t *n_results);
+/* the same, copied device-to-device into caller-owned HBM buffers (any of the three may be NULL) on the handle's
+ * stream: how multi-GPU host code keeps the candidate lists on the device between the phases of a sharded join */
+int32_t apss_results_copy_dev(apss_handle *h, int64_t offset, int64_t count, int32_t *d_q_row, int32_t *d_c_slot,
+                              float *d_score);
 
 /* ---- term-range shards (multi-GPU; one handle per GPU owning dims [term_lo, term_hi)) ----
  * Phase 1, local: a query-type call on a shard handle reports CANDIDATES, pairs whose local partial score
- * p_g satisfies p_g >= theta * |q_g| * |c_g| (|x_g| = L2 norm of x restricted to the shard's dims).  Every
- * pair with total score >= theta passes this test on at least one shard (Cauchy-Schwarz).
+ * p_g satisfies p_g >= theta * |q_g||c_g| / (|q||c|)  (|x_g| = L2 norm of x restricted to the shard's dims, |x| =
+ * norm of the whole row as the caller handed it in, after the value prune).  Every pair with total score >= theta
+ * passes this test on at least one shard, whatever the row norms and whatever the signs of the weights:
+ * p_g <= |q_g||c_g| and sum_g |q_g||c_g| <= |q||c| (Cauchy-Schwarz twice), so if every shard failed the test the
+ * total would be below theta.  The caller must hand every shard the WHOLE row (the library restricts it).
  * Phase 2: the host unions the candidate lists of all shards, every shard fills its exact partial score for
  * each pair with apss_partial_scores_dev, the partials are summed across GPUs (RCCL all-reduce) and
  * thresholded.  Pairs are (query row of the last query batch, candidate slot). */

@@ -1,4 +1,4 @@
-"""bench.py prints ONE JSON line with the fields the driver reads (reduced workload so the test takes seconds)."""
+"""bench.py prints ONE JSON line with the fields the driver reads (reduced workloads so the tests take seconds)."""
 import json
 import os
 import subprocess
@@ -8,24 +8,84 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _one_line(out):
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(lines[0])
 
 
 def test_bench_json_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "60000", "--steps", "2", "--warmup", "1",
                           "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    d = _one_line(out)
+    for k in DRIVER_KEYS:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # the sparse filter: the busiest unit is the LDS pipeline; `frac` is the algorithmic (8 B per visit) figure,
+    # `measured_frac` the counter traffic (only quoted when a committed profile matches the workload byte for byte)
+    assert r["bound"] == "lds" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and "k_probe_coarse" in r["kernel"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    assert "measured_frac" in r and "traffic" in r and "frac_note" in r
+    if r["measured_frac"] is not None:
+        assert 0 < r["measured_frac_of_copy_peak"] <= 1.0 and r["measured_frac"] <= 1.0
+    ex = r["exact_accum"]  # the fp32-accumulate sibling, same run
+    assert "k_probe_wave" in ex["kernel"] and ex["probe_kernel_ms"] > 0 and 0 < ex["frac"] < 1.0
+    assert ex["result_pairs"] == d["result_pairs_per_step"]
+    assert "32768" in str(d["config"]["tile_rows"])
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 1e9  # the north-star floor, even on this reduced workload
     assert abs(d["value"] - d["candidate_pairs_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_bench_skewed_workload_reports_an_mfma_roofline():
+    """C3 with Zipf(1) terms at reduced N: the dense-head block takes the frequent terms, the line names both kernels"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3z1", "--n", "50000", "--steps", "2",
+                          "--warmup", "1", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _one_line(out)
+    for k in DRIVER_KEYS:
+        assert k in d, k
+    assert d["head_terms"] in (64, 128, 256) and d["head_pairs_per_step"] > 0 and "bf16" in d["dtype"]
+    roofs = [d["roofline"]] + [d[k] for k in ("roofline_sparse_filter", "roofline_dense_head") if k in d]
+    assert len(roofs) == 2 and {r["bound"] for r in roofs} == {"lds", "mfma"}
+    m = [r for r in roofs if r["bound"] == "mfma"][0]
+    assert m["unit"] == "TFLOP/s" and m["peak"] == 2500.0 and 0 < m["frac"] < 1.0 and "k_head_gemm" in m["kernel"]
+    assert abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-9
+    assert d["value"] > 1e9 and d["result_pairs_per_step"] > 100
+
+
+def test_bench_stall_exits_nonzero():
+    """a run that does not finish inside its deadline must not report success: watchdog, exit code 3"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "60000", "--steps", "1", "--warmup", "0",
+                          "--deadline", "0.05"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+    assert "stalled in phase" in out.stderr
+
+
+def test_bench_two_ranks_report_both_layouts():
+    """N = 2 rehearsal on one GPU (gloo: both ranks drive GPU 0, collectives on CPU tensors): the headline is the
+    term-range-sharded layout with its all-gather + all-reduce, the candidate-range layout rides along, same result"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "40000",
+                          "--steps", "2", "--warmup", "1", "--backend", "gloo", "--cpu-seconds", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _one_line(out)
+    for k in DRIVER_KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"]["value"] > 0
+    assert "2 term-range shards x 1 candidate ranges" in d["config"]["parallelism"] and "all-reduce" in d["collectives"]
+    ex = d["exchange"]
+    assert ex["term_shards"] == 2 and ex["all_reduce_bytes"] > 0 and ex["union"] >= d["result_pairs_per_step"] > 0
+    comp = d["candidate_range_layout"]
+    assert comp["grid"] == "1 term-range shards x 2 candidate ranges" and comp["value"] > 0
+    assert comp["result_pairs_per_step"] == d["result_pairs_per_step"]

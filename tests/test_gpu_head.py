@@ -1,0 +1,131 @@
+"""GPU parity tests of the dense-head path (apss_head.hpp): the most frequent terms of a skewed (Zipfian) term
+distribution are scored by a bf16 MFMA contraction instead of their posting lists, the rest by the sparse filter under
+the shard rule; the union is re-scored exactly.  Checked against the CPU oracle (CommonUtils.scala:98-117 +
+IndexingWorkerActor.scala:74-111 restated in oracle/): same pair set outside |score - theta| <= 1e-5, scores within 1e-5."""
+import numpy as np
+import pytest
+
+from apss import synth
+from helpers import assert_same_pairs, to_map
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from apss import _lib, engine
+    _lib.lib()
+    return engine
+
+
+def _join(engine, dim, theta, rp, idx, val, **kw):
+    n = len(rp) - 1
+    with engine.ApssIndex(dim, theta, **kw) as ix:
+        q, c, s = ix.insert_and_query(np.arange(n), rp, idx, val)
+        st = ix.stats()
+    return to_map(q, c, s), st
+
+
+@pytest.mark.parametrize("kh", [64, 128, 256])
+@pytest.mark.parametrize("n,dim,nnz,theta", [(3000, 2048, 24, 0.5), (5000, 10000, 50, 0.6), (1500, 400, 12, 0.8)])
+def test_forced_head_block_matches_oracle(engine, oracle, kh, n, dim, nnz, theta):
+    """small Zipf(1) batches with the block forced on: every block width, partially filled query blocks and tiles"""
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=31 + kh, dup_frac=0.1)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 100
+    got, st = _join(engine, dim, theta, rp, idx, val, head_terms=kh, tile_rows=1024)
+    assert st["head_terms"] == min(kh, dim) and st["head_pairs"] > 0 and st["head_flops"] > 0
+    assert_same_pairs(got, want, theta)
+    # the plain path on the same input: identical set, and it visits every posting the hybrid path leaves to the MFMA
+    ref, st0 = _join(engine, dim, theta, rp, idx, val, head_terms=-1, tile_rows=1024)
+    assert st0["head_terms"] == 0 and ref.keys() == got.keys()
+    assert st["posting_visits"] < st0["posting_visits"]
+    # pairs scored: between max(head, tail) and their sum; the plain path's count is exact
+    assert st["candidate_pairs"] <= st0["candidate_pairs"]
+    assert st0["candidate_pairs"] <= st["candidate_pairs"] + st["head_pairs"] + st0["candidate_pairs"] // 2
+
+
+def test_head_pairs_count_is_exact(engine):
+    """`head_pairs` against an independent count: pairs sharing at least one of the block's terms (scipy boolean X X^T
+    restricted to the most frequent terms), self pairs excluded"""
+    import scipy.sparse as sp
+    n, dim, nnz, theta, kh = 4000, 3000, 20, 0.6, 64
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=5, dup_frac=0.05)
+    _, st = _join(engine, dim, theta, rp, idx, val, head_terms=kh)
+    df = np.bincount(idx, minlength=dim)
+    order = np.lexsort((np.arange(dim), -df))  # the library's order: df descending, term id ascending
+    head = np.zeros(dim, bool)
+    head[order[:kh]] = True
+    X = sp.csr_matrix((np.ones(idx.size, np.float32), idx, rp), shape=(n, dim))[:, head]
+    truth = (X @ X.T).nnz - int((X.getnnz(axis=1) > 0).sum())
+    assert st["head_pairs"] == truth
+
+
+def test_c2_size_zipf1_auto_policy(engine, oracle):
+    """BASELINE.json configs[1] at full size (N=100k, dim=10k, nnz=50, Zipf(1), theta=0.5): the library decides on the
+    block by itself; result set against the oracle on a query sample (the oracle needs seconds per thousand queries),
+    and against the plain path on the whole batch"""
+    cfg, rp, idx, val = synth.make_config("c2")
+    n, dim, theta = cfg["n"], cfg["dim"], cfg["theta"]
+    got, st = _join(engine, dim, theta, rp, idx, val)
+    assert st["head_terms"] in (64, 128, 256), st
+    ref, st0 = _join(engine, dim, theta, rp, idx, val, head_terms=-1)
+    assert ref.keys() == got.keys() and len(got) > 1000
+    assert max(abs(got[k] - ref[k]) for k in got) <= 2e-6
+    sample = 1500
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val, 0, sample))
+    assert len(want) > 10
+    assert_same_pairs({k: v for k, v in got.items() if k[0] < sample}, want, theta)
+
+
+def test_streaming_batches_and_frozen_queries(engine, oracle):
+    """the IndexData handler batch after batch (IndexingWorkerActor.scala:123-137) on a handle whose block is chosen at
+    the first batch, then re-evaluated when the store has doubled; then frozen-index queries of a few vectors (the
+    GEMV form of the filter) and of a few hundred (partially filled MFMA query blocks)"""
+    n, dim, nnz, theta = 6000, 3000, 24, 0.55
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=77, dup_frac=0.1)
+    w = oracle.Worker(dim, theta)
+    cuts = [0, 2000, 2300, 4100, 6000]
+    with engine.ApssIndex(dim, theta, head_terms=128, tile_rows=512) as ix:
+        for b0, b1 in zip(cuts[:-1], cuts[1:]):
+            sl = slice(rp[b0], rp[b1])
+            args = (np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])
+            want = to_map(*w.index_data(*args))
+            got = to_map(*ix.insert_and_query(*args))
+            assert_same_pairs(got, want, theta)
+            assert ix.stats()["head_terms"] == 128
+        full = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+        for b0, b1 in [(10, 13), (100, 116), (1000, 1400)]:
+            sl = slice(rp[b0], rp[b1])
+            got = to_map(*ix.query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl]))
+            assert_same_pairs(got, {k: v for k, v in full.items() if b0 <= k[0] < b1}, theta)
+
+
+def test_unnormalised_rows_and_fallback(engine, oracle):
+    """rows of norm != 1 (the rule divides by the full norms: no pair is lost), then a batch with a negative weight:
+    the handle gives the block up for good and answers through the plain path"""
+    n, dim, nnz, theta = 3000, 1500, 16, 0.4
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=9, dup_frac=0.1)
+    rng = np.random.default_rng(3)
+    scale = np.repeat(rng.uniform(0.4, 1.3, size=n), nnz)
+    val2 = val * scale
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val2))
+    got, st = _join(engine, dim, theta, rp, idx, val2, head_terms=64)
+    assert st["head_terms"] == 64 and len(want) > 100
+    assert_same_pairs(got, want, theta)
+    val3 = val.copy()
+    val3[5::7] *= -1.0
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val3))
+    got, st = _join(engine, dim, theta, rp, idx, val3, head_terms=64)
+    assert st["head_terms"] == 0
+    assert_same_pairs(got, want, theta)
+    # a non-negative store with the block, then a query with a negative weight
+    with engine.ApssIndex(dim, theta, head_terms=64) as ix:
+        ix.insert(np.arange(n), rp, idx, val)
+        assert ix.stats()["rows"] == n
+        q = to_map(*ix.query(np.arange(50), rp[:51], idx[:rp[50]], val3[:rp[50]]))
+        w = oracle.Worker(dim, theta)
+        w.index_data(np.arange(n), rp, idx, val)
+        want = to_map(*w.index_data(np.arange(50), rp[:51], idx[:rp[50]], val3[:rp[50]], query_only=True))
+        assert_same_pairs(q, want, theta)
+        assert ix.stats()["head_terms"] == 0

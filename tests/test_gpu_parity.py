@@ -75,7 +75,7 @@ def test_join_cut_into_several_launches(apss_mod, monkeypatch, path):
     """a long join runs as a sequence of launches over groups of tiles (here: one tile per launch); same pairs and
     the same work counters as the single launch"""
     from apss import _lib
-    monkeypatch.setenv("APSS_TILES_PER_LAUNCH", "1")
+    monkeypatch.setenv("APSS_DEBUG", "tiles_per_launch=1")
     z = np.load(os.path.join(GOLDEN, "mini_zipf_t05.npz"))
     dim, theta = int(z["dim"]), float(z["theta"])
     got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=128,
@@ -255,10 +255,14 @@ def test_c2_shape_reduced(apss_mod, oracle):
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
     assert len(want) > 500
     from apss import _lib
-    for tr, fl in ((0, 0), (8192, 0), (0, _lib.FLAG_EXACT_ACCUM), (0, _lib.FLAG_FORCE_GENERAL)):
-        got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=tr, flags=fl)
+    visits = int(synth.workload_counts(dim, rp, idx)[1])
+    for tr, fl, head in ((0, 0, -1), (0, 0, 0), (8192, 0, -1), (0, _lib.FLAG_EXACT_ACCUM, 0), (0, _lib.FLAG_FORCE_GENERAL, 0)):
+        got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, tile_rows=tr, flags=fl, head_terms=head)
         assert_same_pairs(got, want, theta)
-        assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
+        if st["head_terms"]:  # the library moved the most frequent terms to the dense block: their postings are not visited
+            assert (tr, fl, head) == (0, 0, 0) and st["posting_visits"] < visits // 4 and st["head_pairs"] > 0
+        else:
+            assert st["posting_visits"] == visits
 
 
 def test_c3_shape_properties(apss_mod):
@@ -401,7 +405,7 @@ def test_queries_longer_than_a_workgroup_use_the_two_pass_join(apss_mod, oracle,
     """queries of > 512 terms are cut into parts that share the accumulators; both filter kernels (512 and 1024 threads);
     many near-copies of one long row overflow the survivor list of a part (> 512 crossings in one tile)"""
     if cx_tile:
-        monkeypatch.setenv("APSS_CX_TILE", cx_tile)
+        monkeypatch.setenv("APSS_DEBUG", "cx_tile=" + cx_tile)
     n, dim, theta = 2500, 6000, 0.7
     rp, idx, val = _long_rows(n, dim, seed=77)
     # 700 more near-copies of row 0, made long: every one of them crosses in the same tile for each of the others
@@ -452,14 +456,14 @@ def test_stratified_fullsize_property_reduced():
     assert out["tiles"] == 31 and out["probe_launches"] == 1 and out["max_abs_score_error"] <= 1e-5
 
 
-@pytest.mark.parametrize("hook", [None, "APSS_CX_CHUNK8", "APSS_CX_U3"])
+@pytest.mark.parametrize("hook", [None, "chunk8", "window=3", "window=2"])
 def test_candidate_pair_count_is_exact_when_the_window_overflows(apss_mod, monkeypatch, hook):
     """`candidate_pairs` (the benchmark's unit) against an independent count, scipy's boolean X X^T, at C3's segment
     density (33 postings per (tile, term)); the hooks shrink the register window so that most rounds take the
     overflow path (first touches are then counted per lane, not per wave)"""
     import scipy.sparse as sp
     if hook:
-        monkeypatch.setenv(hook, "1")
+        monkeypatch.setenv("APSS_DEBUG", hook)
     n, dim, nnz, theta = 33_000, 100_000, 100, 0.7
     rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=3, dup_frac=0.05)
     X = sp.csr_matrix((np.ones(idx.size, np.float32), idx, rp), shape=(n, dim))
@@ -478,10 +482,9 @@ def test_global_atomic_index_build_matches_the_lds_build(apss_mod, monkeypatch, 
     z = np.load(os.path.join(GOLDEN, "mini_zipf_t05.npz"))
     dim, theta = int(z["dim"]), float(z["theta"])
     flags = {"two_pass": 0, "exact_wave": _lib.FLAG_EXACT_ACCUM}[path]
-    monkeypatch.setenv("APSS_BUILD_LDS", "1")  # (small batches default to the atomic build)
+    monkeypatch.setenv("APSS_DEBUG", "build_lds")  # (small batches default to the atomic build)
     ref, st_ref = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=256, flags=flags)
-    monkeypatch.delenv("APSS_BUILD_LDS")
-    monkeypatch.setenv("APSS_BUILD_ATOMIC", "1")
+    monkeypatch.setenv("APSS_DEBUG", "build_atomic")
     got, st = _gpu_join(apss_mod, dim, theta, z["rowptr"], z["indices"], z["values"], tile_rows=256, flags=flags)
     assert got.keys() == ref.keys() and st["candidate_pairs"] == st_ref["candidate_pairs"]
     assert st["posting_visits"] == st_ref["posting_visits"] and st["nnz"] == st_ref["nnz"]
@@ -529,3 +532,27 @@ def test_handles_are_independent_across_threads(apss_mod, oracle):
             t.start()
             t.join()
     assert_same_pairs(stream, {k: v for k, v in want.items() if k[0] >= (k[1] // 1000) * 1000}, theta)
+
+
+def test_results_are_invalidated_by_an_insert(apss_mod):
+    """the results of a query-type call point into the store; an insert that grows the store frees those arrays, so the
+    result calls answer APSS_E_STATE afterwards instead of reading freed HBM"""
+    import torch
+    from apss import _lib
+    n, dim, nnz, theta = 600, 300, 10, 0.4
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=8, dup_frac=0.2)
+    with apss_mod.ApssIndex(dim, theta, tile_rows=64) as ix:
+        q, c, s = ix.insert_and_query(np.arange(100), rp[:101], idx[:rp[100]], val[:rp[100]])
+        assert len(q) > 0 and ix.result_count() == len(q)
+        ix.insert(np.arange(100, n), rp[100:] - rp[100], idx[rp[100]:], val[rp[100]:])  # forces reallocation of the store
+        for call in (ix.result_count, ix.fetch, ix.results_dev):
+            with pytest.raises(apss_mod.ApssError) as e:
+                call()
+            assert e.value.code == _lib.E_STATE
+        with pytest.raises(apss_mod.ApssError) as e:
+            ix.partial_scores_dev(torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"),
+                                  torch.zeros(1, dtype=torch.float32, device="cuda"))
+        assert e.value.code == _lib.E_STATE
+        # and the next query-type call answers as usual
+        q2, c2, s2 = ix.self_join()
+        assert len(q2) >= len(q)

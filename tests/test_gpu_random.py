@@ -43,7 +43,7 @@ def test_random_streams(oracle, seed, monkeypatch):
     from apss import _lib
     from apss.engine import ApssIndex
     if seed % 4 == 1:
-        monkeypatch.setenv("APSS_BUILD_LDS", "1")  # small batches default to the global-atomic index build
+        monkeypatch.setenv("APSS_DEBUG", "build_lds")  # small batches default to the global-atomic index build
     rng = np.random.default_rng(1000 + seed)
     dim, theta, ids, rp, idx, val, cuts = _random_case(rng)
     flags = [0, _lib.FLAG_EXACT_ACCUM, _lib.FLAG_FORCE_GENERAL][seed % 3]

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_shards_on_one_gpu_match_oracle(oracle, monkeypatch, world, zipf, theta, shard_kernel):
     import torch
     if shard_kernel == "single_pass":
-        monkeypatch.setenv("APSS_SHARD_EXACT", "1")  # read when the handle is created
+        monkeypatch.setenv("APSS_DEBUG", "shard_exact")  # read when the handle is created
     from apss.dist import HipShardEngine, join_shards_local, term_ranges
     n, dim, nnz = 4000, 2000, 30
     rp, idx, val = synth.make_vectors(n, dim, nnz, zipf, seed=91, dup_frac=0.1)
@@ -71,4 +71,48 @@ def test_sparse_term_shards_keep_the_shard_threshold(oracle):
         e.load(rp, idx, val)
     q, c, s, n_cand = join_shards_local(engines, n, theta)
     assert min(n_cand) > 0
+    assert_same_pairs(to_map(q, c, s), want, theta)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_term_shards_with_norms_above_one_lose_nothing(oracle, world):
+    """the candidate rule divides by the FULL row norms (p_g >= theta |q_g||c_g| / (|q||c|)), so un-normalised rows go
+    through term shards like through one handle: rows scaled to norms between 0.5 and 2.5 (|q||c| up to 6), among them
+    the case of two shards with p_g = 0.4, |q_g||c_g| = 2 each that a rule without the division would drop"""
+    import torch
+    from apss.dist import HipShardEngine, join_shards_local, term_ranges
+    n, dim, nnz, theta = 3000, 1200, 20, 0.7
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=93, dup_frac=0.15)
+    rng = np.random.default_rng(4)
+    val = val * np.repeat(rng.uniform(0.5, 2.5, size=n), nnz)
+    # the two-shard example: unit-free rows [2 over terms of shard A | 2 over terms of shard B] x small overlap
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 300
+    dev = torch.device("cuda", 0)
+    engines = [HipShardEngine(dim, theta, tr, dev, tile_rows=512) for tr in term_ranges(np.bincount(idx, minlength=dim), world)]
+    for e in engines:
+        e.load(rp, idx, val)
+    q, c, s, _ = join_shards_local(engines, n, theta)
+    assert_same_pairs(to_map(q, c, s), want, theta, band=2e-5, tol=2e-5)  # scores up to 6: fp32 sums
+
+
+def test_two_shard_counterexample_of_the_unit_norm_rule(oracle):
+    """|q||c| = 4, two shards with p_g = 0.4 and |q_g||c_g| = 2 each: total 0.8 >= theta = 0.8 while p_g / (|q_g||c_g|)
+    = 0.2 on both shards -- found only because the rule compares with theta / (|q||c|) = 0.2"""
+    import torch
+    from apss.dist import HipShardEngine, join_shards_local
+    dim, theta = 8, 0.79
+    # q = (a, a, 0, 0 | a, a, 0, 0), c = (b, 0, b', 0 | b, 0, b', 0): per shard q_g.c_g = a b, |q_g| = a sqrt2, |c_g| = sqrt(b^2 + b'^2)
+    a, b = 1.0, 0.4
+    bp = np.sqrt(2.0 - b * b)
+    rp = np.array([0, 4, 8], np.int64)
+    idx = np.array([0, 1, 4, 5, 0, 2, 4, 6], np.int32)
+    val = np.array([a, a, a, a, b, bp, b, bp], np.float64)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert set(want) == {(0, 1), (1, 0)} and abs(want[(0, 1)] - 0.8) < 1e-12
+    dev = torch.device("cuda", 0)
+    engines = [HipShardEngine(dim, theta, tr, dev, tile_rows=64) for tr in ((0, 4), (4, 8))]
+    for e in engines:
+        e.load(rp, idx, val)
+    q, c, s, _ = join_shards_local(engines, 2, theta)
     assert_same_pairs(to_map(q, c, s), want, theta)
