@@ -4,7 +4,10 @@
 // posting lists are N long and the inverted-index probe (IndexingWorkerActor.scala:101-109) visits df_t^2 postings for
 // each of them.  Those terms are taken OUT of the inverted index and kept as a dense block instead: row c of
 //     W [rows x KH]  (bf16),   w_c = c_H * |c| / |c_H|     (c_H = the row restricted to the KH head terms)
-// so that  w_q . w_c = cos_H(q, c) * |q| |c|.  The arithmetic is the reference's dot product
+// so that  w_q . w_c = cos_H(q, c) * |q| |c|.  Layout in HBM: tiles of 64 rows; inside a tile CHUNK-major --
+// W[tile][chunk k/8][row % 64][k % 8], 16-B chunks -- so that a tile is copied into LDS linearly (LDS-DMA writes
+// wave-uniform base + lane * 16) and the MFMA fragment of k-step kk is 32 consecutive rows of one chunk: a contiguous,
+// bank-conflict-free LDS read at an immediate offset (no swizzle, no padding, no address registers).  The arithmetic is the reference's dot product
 // (CommonUtils.scala:110-115) restricted to the head dims, as a [queries x KH] x [KH x candidates] bf16 contraction
 // on the matrix cores.
 //
@@ -35,6 +38,8 @@ typedef __attribute__((ext_vector_type(16))) float apss_f32x16;
 constexpr int kHeadQBlock = 512;   // query slots per workgroup (8 waves x 64)
 constexpr int kHeadCTile = 64;     // candidate rows per LDS tile
 constexpr uint32_t kNoTerm = 0x7fffffffu;  // idx_tail value of an entry that lives in the dense block
+// candidate rows per LDS tile of k_head_gemm
+__host__ __device__ constexpr int head_tile_rows(int) { return kHeadCTile; }
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rn(float f) {
   const uint32_t u = __float_as_uint(f);
@@ -56,28 +61,38 @@ __global__ void k_df_sample(const int64_t *rowptr, const int32_t *idx, int64_t n
 // ---------------------------------------------------------------------------------------------------------
 // k_head_pack: one wave per row of a CSR batch -> its row of W, its tail ratio |x_T| / |x| (the scale of the sparse
 // filter's shard rule), and (store rows) the entry-wise term array the index build reads, head entries masked out.
+// element offset of (row, chunk) in a tiled W of width kh
+__host__ __device__ __forceinline__ int64_t head_chunk_off(int64_t row, int chunk, int kh) {
+  return (((row >> 6) * (kh / 8) + chunk) * kHeadCTile + (row & 63)) * 8;
+}
+
 struct HeadPackArgs {
   const int64_t *rowptr;   // absolute offsets into idx / val
   const int32_t *idx;
   const float *val;
-  int64_t row0, row1;      // rows [row0, row1) of that CSR
+  int64_t row0, row1;      // rows [row0, row1) of that CSR are packed; W rows [w_row0 + row1 - row0, w_pad) are zeroed
   const int32_t *head_pos; // [dim] position of a term in the dense block, -1 = tail term
   int32_t kh;              // 64 | 128 | 256
-  uint16_t *W;             // [.. x kh] bf16 bits; row r is written at W + (w_row0 + r - row0) * kh
-  int64_t w_row0;
-  float *ratio_t;          // [..] |x_T| / |x| per row, same indexing as W rows
+  uint16_t *W;             // tiled; CSR row r lands in W row w_row0 + r - row0
+  int64_t w_row0, w_pad;   // w_pad: a multiple of 64 (the GEMM reads whole tiles)
+  float *ratio_t;          // [..] |x_T| / |x| per row, indexed like the W rows
   int32_t *idx_tail;       // same extent as idx (may be null): idx with head entries replaced by kNoTerm
   unsigned int *head_nonempty;  // += rows with at least one head entry
 };
 
-__global__ __launch_bounds__(256) void k_head_pack(HeadPackArgs a) {
-  __shared__ uint16_t rowbuf[4][256];
+// one wave per W row, 8 rows (one 128-B line per chunk) per workgroup; the workgroup covers W rows [8 g, 8 g + 8)
+__global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t rowbuf[8][256];
   __shared__ unsigned int nz;
   if (threadIdx.x == 0) nz = 0;
   __syncthreads();
   const int wv = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int64_t row = a.row0 + (int64_t)blockIdx.x * 4 + wv;
-  if (row < a.row1) {
+  const int64_t g0 = (a.w_row0 / 8 + blockIdx.x) * 8;  // first W row of this group
+  const int64_t wr = g0 + wv;
+  const int64_t row = a.row0 + (wr - a.w_row0);         // CSR row of this wave
+  const bool real = wr >= a.w_row0 && row < a.row1;
+  for (int i = lane; i < a.kh; i += kWave) rowbuf[wv][i] = 0;
+  if (real) {
     const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
     float full2 = 0.f, h2 = 0.f, t2 = 0.f;
     for (int64_t k = b + lane; k < e; k += kWave) {
@@ -94,16 +109,11 @@ __global__ __launch_bounds__(256) void k_head_pack(HeadPackArgs a) {
       t2 += __shfl_xor(t2, o);
     }
     const float scale = h2 > 0.f ? sqrtf(full2 / h2) : 0.f;
-    for (int i = lane; i < a.kh; i += kWave) rowbuf[wv][i] = 0;
-    // (LDS operations of one wave execute in order: the zero fill lands before the entries, the read-out after them)
+    // (LDS operations of one wave execute in order: the zero fill above lands before these entries)
     for (int64_t k = b + lane; k < e; k += kWave) {
       const int32_t hp = a.head_pos[a.idx[k]];
       if (hp >= 0) rowbuf[wv][hp] = f32_to_bf16_rn(a.val[k] * scale);
     }
-    const int64_t wr = a.w_row0 + (row - a.row0);
-    uint16_t *dst = a.W + wr * a.kh;
-    for (int i = lane * 2; i < a.kh; i += kWave * 2)
-      *reinterpret_cast<uint32_t *>(dst + i) = *reinterpret_cast<const uint32_t *>(&rowbuf[wv][i]);
     if (lane == 0) {
       // rounded UP a hair: the scale only ever lowers the sparse filter's threshold
       a.ratio_t[wr] = full2 > 0.f ? fminf(1.0f, sqrtf(t2 / full2) * 1.000001f) : 0.f;
@@ -111,15 +121,15 @@ __global__ __launch_bounds__(256) void k_head_pack(HeadPackArgs a) {
     }
   }
   __syncthreads();
+  // write-out: unit u = (chunk c, row j of the group): 8 rows x 16 B = one 128-B line per chunk
+  const int cpr = a.kh / 8;
+  for (int u = threadIdx.x; u < cpr * 8; u += blockDim.x) {
+    const int c = u >> 3, j = u & 7;
+    const int64_t w = g0 + j;
+    if (w >= a.w_row0 && w < a.w_pad)
+      *reinterpret_cast<uint4 *>(a.W + head_chunk_off(w, c, a.kh)) = *reinterpret_cast<const uint4 *>(&rowbuf[j][c * 8]);
+  }
   if (threadIdx.x == 0 && nz && a.head_nonempty) atomicAdd(a.head_nonempty, nz);
-}
-
-// zero rows [r0, r1) of a [.. x kh] bf16 matrix (the padding a GEMM tile may read past the last row)
-__global__ void k_head_zero_rows(uint16_t *W, int64_t r0, int64_t r1, int32_t kh) {
-  const int64_t n = (r1 - r0) * kh / 8;  // uint4 = 8 bf16
-  uint4 *p = reinterpret_cast<uint4 *>(W + r0 * kh);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -131,22 +141,21 @@ __global__ void k_head_zero_rows(uint16_t *W, int64_t r0, int64_t r1, int32_t kh
 // of 8 bf16 = 128 VGPRs at KH = 256) in registers for the whole kernel and the panel's candidate rows stream past it:
 // tiles of 64 candidates x KH (32 KB at KH = 256) are copied global -> LDS by LDS-DMA (buffer -> lds, 16 B per lane,
 // 1 KiB per wave-instruction) into two buffers, tile t + 1 in flight while the 64 MFMAs of tile t run; one barrier per
-// tile.  The LDS image is linear in DMA order (the destination is wave-uniform base + lane * 16), so the bank swizzle
-// sits on the SOURCE address: LDS chunk (row, p) holds source chunk p ^ s(row), and a fragment read of 16 lanes (16 rows,
-// the same k) then covers all 64 banks once.
-// Grid: blockIdx -> (panel = blockIdx % P, query block descending).  Hardware sends consecutive workgroups to
-// consecutive XCDs, so with P a multiple of 8 every workgroup of an XCD streams a panel of the same residue class: the
-// panel's tiles are read from HBM once per XCD and then served by that XCD's L2 to the other workgroups sweeping it.
+// tile.  The tile's chunk-major layout (top of this file) makes the copy linear and every fragment read contiguous.
+// Grid: blockIdx -> (panel = blockIdx % P, query block descending); panel p = the tiles t with t % P == p.  Hardware
+// sends consecutive workgroups to consecutive XCDs, so with P a multiple of 8 every workgroup of an XCD streams panels
+// of one residue class: a panel's tiles are read from HBM once per XCD and then served by that XCD's L2 to the other
+// workgroups sweeping it.
 // Stored queries (self-join, insert-and-query): D is symmetric over the batch, so candidate tiles ABOVE a query block
 // are skipped and an element strictly below it reports both (q, c) and (c, q).
 struct HeadGemmArgs {
-  const uint16_t *Wq;   // query rows: indexed by query SLOT when the batch is stored (Wq == Wc), else by query row
-  const uint16_t *Wc;   // candidate rows by slot, zero rows up to the tile boundary
+  const uint16_t *Wq;   // query rows (tiled): indexed by query SLOT when the batch is stored (Wq == Wc), else by query row
+  const uint16_t *Wc;   // candidate rows by slot (tiled), zero rows up to the tile boundary
   int64_t wq_rows;      // rows of Wq that may be read
   int64_t n_rows;       // candidate slots
   int64_t q_slot_base;  // slot of query row 0 when the batch is stored in the index, else -1
   int32_t nq;
-  int32_t n_qblocks, n_panels, tiles_per_panel, n_ctiles;
+  int32_t n_qblocks, n_panels, n_ctiles;  // n_ctiles: candidate tiles of head_tile_rows(KH) rows
   int64_t qblock0;      // first query block's first slot (a multiple of 512)
   const int64_t *q_ext, *c_ext;
   float thr;
@@ -157,14 +166,21 @@ struct HeadGemmArgs {
   unsigned long long *head_pairs;  // += elements with a positive dot (pairs sharing a head term), self pairs included
 };
 
-template <int KH>
+template <int KH, bool COUNT = true>
 __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
   constexpr int KS = KH / 16;                 // k-steps of the 32x32x16 MFMA
+  constexpr int SPK = 16 / KS;                // epilogue scan steps (2 accumulators each) per k-step of the other half
+  static_assert(SPK * KS == 16, "KH is 64, 128 or 256");
   constexpr int ROWB = KH * 2;                // bytes per row
   constexpr int CPR = KH / 8;                 // 16-B chunks per row
-  constexpr int TILEB = kHeadCTile * ROWB;    // bytes per LDS tile
+  constexpr int SUB = 1;                      // 64-row sub-tiles per LDS tile (32-KB tiles at KH < 256, SUB = 256 / KH, measured
+  constexpr int CT = kHeadCTile * SUB;        //   slower: narrow blocks are bound by the epilogue, not by the barrier)
+  constexpr int NB = CT / 32;                 // 32-candidate column blocks per tile
+  constexpr int SUBB = kHeadCTile * ROWB;     // bytes per sub-tile
+  constexpr int TILEB = CT * ROWB;            // bytes per tile (contiguous in HBM: consecutive 64-row tiles of W)
   constexpr int PIECES = TILEB / 1024;        // 1-KiB DMA pieces per tile
   constexpr int PPW = PIECES / 8;             // pieces per wave
+  constexpr int PF = 2;                       // B fragments requested ahead of the MFMAs that use them
   static_assert(PIECES % 8 == 0, "every wave copies the same number of pieces");
   __shared__ __attribute__((aligned(1024))) unsigned char ldsb[2 * TILEB];
   __shared__ float scratch[8 * 16 * kWave];  // reporting path only: one 32 x 32 accumulator block per wave
@@ -178,14 +194,18 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
   const int64_t B0 = a.qblock0 + (int64_t)qb * kHeadQBlock;  // first query slot of this block
   const int64_t qs0 = stored ? a.q_slot_base : 0;            // slot of query row 0
 
-  int t_lo = panel * a.tiles_per_panel;
-  int t_hi = min(a.n_ctiles, t_lo + a.tiles_per_panel);
-  if (stored) t_hi = min(t_hi, (int)((B0 + kHeadQBlock) / kHeadCTile));  // tiles above the block: done by the block that owns them
+  // panel p = candidate tiles p, p + P, p + 2P, ...: interleaved, so that the triangle of a stored batch (tiles above
+  // the query block are skipped: the block that owns them reports the mirrored pairs) is cut evenly over the panels,
+  // hence over the XCDs
+  const int t_lo = panel, t_step = a.n_panels;
+  int t_hi = a.n_ctiles;
+  if (stored) t_hi = min(t_hi, (int)((B0 + kHeadQBlock) / CT));
   if (t_lo >= t_hi) return;
 
-  // ---- A fragments: lane (r, hh) of block m holds W[slot][16 kk + 8 hh .. + 8) ----
+  // ---- A fragments: lane (r, hh) of block m holds W[slot][16 kk + 8 hh .. + 8) = chunk 2 kk + hh of its row; the 32
+  // lanes of a half read 32 consecutive rows of one chunk: 512 contiguous bytes ----
   apss_bf16x8 af[2][KS];
-  const int64_t wslot0 = B0 + 64 * wv;
+  const int64_t wslot0 = B0 + 64 * wv;  // a multiple of 64: the wave's 64 slots are one tile of Wq
   bool wave_live = false;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -193,130 +213,156 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
     const int64_t row = s - qs0;
     const bool ok = row >= 0 && row < a.nq && s < a.wq_rows;
     wave_live |= ok;
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq + (ok ? s : 0) * KH) + hh;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq) + ((ok ? wslot0 : 0) / kHeadCTile) * (CPR * kHeadCTile) + 32 * m + r;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = src[2 * kk];
+      if (ok) v = src[(2 * kk + hh) * kHeadCTile];
       af[m][kk] = __builtin_bit_cast(apss_bf16x8, v);
     }
   }
   wave_live = __any(wave_live);  // a wave without a query row copies tiles but computes nothing
 
-  // ---- tile copy: wave w moves pieces w * PPW .. of the tile; LDS chunk g = piece * 64 + lane <- source chunk ----
-  auto swz = [](int row) { return CPR >= 16 ? (row & 15) : ((row >> 1) & (CPR - 1)); };
-  uint32_t src_off[PPW];  // byte offset of this lane's source chunk inside a tile
-#pragma unroll
-  for (int p = 0; p < PPW; ++p) {
-    const int g = (wv * PPW + p) * 64 + ln;
-    const int row = g / CPR, pc = g % CPR;
-    src_off[p] = (uint32_t)(row * ROWB + ((pc ^ swz(row)) & (CPR - 1)) * 16);
-  }
+  // ---- tile copy by LDS-DMA: a tile is TILEB contiguous bytes in HBM and lands in LDS as it is; wave w moves the
+  // 1-KiB pieces (= chunks) w * PPW .. , lane l the 16 bytes of row l ----
   auto copy_tile = [&](const int t, const int buf) {
-    const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * TILEB;
+    const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * TILEB + ln * 16;
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(tsrc + src_off[p]),
+          (const __attribute__((address_space(1))) void *)(tsrc + (wv * PPW + p) * 1024),
           (__attribute__((address_space(3))) void *)(ldsb + buf * TILEB + (wv * PPW + p) * 1024), 16, 0, 0);
     }
   };
-  // fragment read offsets: lane (r, hh) of column block n reads row 32 n + r, chunk (2 kk + hh) ^ s(row)
-  uint32_t rd_row[2], rd_sw[2];
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int row = 32 * n + r;
-    rd_row[n] = (uint32_t)(row * ROWB);
-    rd_sw[n] = (uint32_t)swz(row);
-  }
+  // fragment reads: lane (r, hh) of column block n reads row 32 n + r of chunk 2 kk + hh: one address per lane, the
+  // k-step and the column block are immediate offsets
+  const uint32_t rd_lane = (uint32_t)(hh * 1024 + r * 16);
 
-  uint32_t n_pos = 0;  // positive elements seen by this lane (< 2^32: at most 128 per tile)
-  copy_tile(t_lo, 0);
-  for (int t = t_lo; t < t_hi; ++t) {
-    const int buf = (t - t_lo) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
-    __syncthreads();                                   // ... and everyone's; the other buffer's readers are done
-    if (t + 1 < t_hi) copy_tile(t + 1, buf ^ 1);
-    if (!wave_live) continue;
+  unsigned long long n_pos = 0;  // positive elements seen by this lane
+  float *const sc = scratch + wv * (16 * kWave);
 
-    apss_f32x16 acc[2][2];
+  // ---- the epilogue of one 64 x 32 half (column block n of a tile): nothing of D is stored.  `scan` folds two of its
+  // 32 accumulators per call into the running maximum and the count of positive elements; it is called between the
+  // MFMAs of the OTHER half, whose matrix-core time hides it.  `finish` closes the half: add the count (an element
+  // strictly below a stored query block stands for (q, c) and, when c is a query of the batch too, for (c, q)) and,
+  // when some element reached the threshold, report.
+  struct Half {
+    float mx;
+    uint32_t pos;
+  };
+  auto scan = [&](Half &hf, const apss_f32x16 (&ac)[2], const int step) {  // step 0..15: elements 2 step, 2 step + 1 of 32
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-    const unsigned char *tb = ldsb + buf * TILEB;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      apss_bf16x8 bf[2];
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const uint32_t chunk = ((uint32_t)(2 * kk + hh) ^ rd_sw[n]) & (uint32_t)(CPR - 1);
-        bf[n] = __builtin_bit_cast(apss_bf16x8, *reinterpret_cast<const uint4 *>(tb + rd_row[n] + chunk * 16u));
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][kk], bf[n], acc[m][n], 0, 0, 0);
+    for (int j = 0; j < 2; ++j) {
+      const int e = 2 * step + j;
+      const float v = ac[e >> 4][e & 15];
+      hf.mx = fmaxf(hf.mx, v);
+      if (COUNT) hf.pos += v > 0.f ? 1u : 0u;
     }
-
-    // ---- epilogue: nothing is stored; count the positive elements, find the few at or above the threshold ----
-    const int64_t c_row0 = (int64_t)t * kHeadCTile;
-    // strictly below the query block (and inside the stored batch): the mirrored element is computed by nobody
-    const bool below = stored && c_row0 + kHeadCTile <= B0;
-    float mx = 0.f;
+  };
+  auto finish = [&](Half &hf, const apss_f32x16 (&ac)[2], const int64_t cb_row0) {  // cb_row0: the half's first candidate row
+    const bool below = stored && cb_row0 + 32 <= B0;
+    const int64_t c = cb_row0 + r;
+    n_pos += (below && c >= qs0) ? 2u * hf.pos : hf.pos;
+    if (__any(hf.mx >= a.thr)) {
+      // rare (a tile holding a near-duplicate, or the block's own diagonal): the accumulators go through a wave-private
+      // LDS scratch one 32 x 32 block at a time, so that the reporting loop is a real loop
+      const int64_t cext = c < a.n_rows ? a.c_ext[c] : 0;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      uint32_t pos = 0;
+      for (int m = 0; m < 2; ++m) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          mx = fmaxf(mx, acc[m][n][i]);
-          pos += acc[m][n][i] > 0.f ? 1u : 0u;
-        }
-      // an element below the block stands for (q, c) and, when c is itself a query of the batch, for (c, q) too
-      n_pos += (below && c_row0 + 32 * n + r >= qs0) ? 2u * pos : pos;
-    }
-
-    if (__any(mx >= a.thr)) {
-      // rare (a tile holding a near-duplicate, or the block's own diagonal): the wave's accumulators go through a
-      // wave-private LDS scratch one 32 x 32 block at a time, so that the reporting loop is a real loop
-      float *sc = scratch + wv * (16 * kWave);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sc[i * kWave + ln] = acc[m][n][i];
-          const int64_t c = c_row0 + 32 * n + r;
-          const int64_t cext = c < a.n_rows ? a.c_ext[c] : 0;
+        for (int i = 0; i < 16; ++i) sc[i * kWave + ln] = ac[m][i];
 #pragma unroll 1
-          for (int i = 0; i < 16; ++i) {
-            const float v = sc[i * kWave + ln];
-            if (!__any(v >= a.thr)) continue;
-            const int64_t s = wslot0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int64_t qrow = s - qs0;
-            bool ok = v >= a.thr && qrow >= 0 && qrow < a.nq && c < a.n_rows;
-            if (ok) ok = a.q_ext[qrow] != cext;  // self-exclusion by external id (IWA:91)
-            const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
-            if (ok && o < a.res_cap) {
-              a.res_q[o] = (int32_t)qrow;
-              a.res_c[o] = (int32_t)c;
-              a.res_s[o] = v;  // filter score; k_rescore replaces it
-            }
-            const bool ok2 = ok && below && c >= qs0;  // the mirrored pair: c as the query, q's slot as the candidate
-            const uint64_t o2 = wave_append(ok2, &a.counters[kCtrResults]);
-            if (ok2 && o2 < a.res_cap) {
-              a.res_q[o2] = (int32_t)(c - qs0);
-              a.res_c[o2] = (int32_t)s;
-              a.res_s[o2] = v;
-            }
+        for (int i = 0; i < 16; ++i) {
+          const float v = sc[i * kWave + ln];
+          if (!__any(v >= a.thr)) continue;
+          const int64_t s = wslot0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          const int64_t qrow = s - qs0;
+          bool ok = v >= a.thr && qrow >= 0 && qrow < a.nq && c < a.n_rows;
+          if (ok) ok = a.q_ext[qrow] != cext;  // self-exclusion by external id (IWA:91)
+          const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+          if (ok && o < a.res_cap) {
+            a.res_q[o] = (int32_t)qrow;
+            a.res_c[o] = (int32_t)c;
+            a.res_s[o] = v;  // filter score; k_rescore replaces it
+          }
+          const bool ok2 = ok && below && c >= qs0;  // the mirrored pair: c as the query, q's slot as the candidate
+          const uint64_t o2 = wave_append(ok2, &a.counters[kCtrResults]);
+          if (ok2 && o2 < a.res_cap) {
+            a.res_q[o2] = (int32_t)(c - qs0);
+            a.res_c[o2] = (int32_t)s;
+            a.res_s[o2] = v;
           }
         }
+      }
     }
+    hf.mx = 0.f;
+    hf.pos = 0;
+  };
+  // the 32 MFMAs of one half: D[64 slots][32 candidates of column block n] over the whole K.  The B fragments come
+  // from LDS PF k-steps ahead of their MFMAs (a read that an MFMA waits for exposes its whole latency);
+  // `between(kk)` runs after the two MFMAs of every k-step
+  auto ldfrag = [&](const unsigned char *tb, const int n, const int kk) {
+    // column block n of the LDS tile: 64-row sub-tile n / 2 (SUBB bytes each), rows 32 (n % 2) .. of it
+    return __builtin_bit_cast(apss_bf16x8, *reinterpret_cast<const uint4 *>(tb + rd_lane + kk * 2048 + (n >> 1) * SUBB + (n & 1) * 512));
+  };
+  auto mma_half = [&](apss_f32x16 (&ac)[2], const unsigned char *tb, const int n, auto &&between) {
+    apss_bf16x8 bf[PF];
+#pragma unroll
+    for (int j = 0; j < PF && j < KS; ++j) bf[j] = ldfrag(tb, n, j);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const apss_bf16x8 b = bf[kk % PF];
+      if (kk + PF < KS) bf[kk % PF] = ldfrag(tb, n, kk + PF);
+      if (kk == 0) {
+        const apss_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][kk], b, zero, 0, 0, 0);
+        ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][kk], b, zero, 0, 0, 0);
+      } else {
+        ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][kk], b, ac[0], 0, 0, 0);
+        ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][kk], b, ac[1], 0, 0, 0);
+      }
+      between(kk);
+    }
+  };
+
+  // Software pipeline by halves, no second accumulator set: the 32-candidate column blocks of a tile alternate between
+  // two accumulator pairs; while the matrix cores work on block b the vector unit scans block b - 1 (the last block of
+  // tile t - 1 when b = 0).
+  apss_f32x16 acc0[2], acc1[2];
+  Half h0{0.f, 0u}, h1{0.f, 0u};
+  int64_t pend = -1;  // first candidate row of the column block whose scan is pending in acc1 / h1 (-1: none)
+  copy_tile(t_lo, 0);
+  int buf = 0;
+  for (int t = t_lo; t < t_hi; t += t_step, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
+    __syncthreads();                                   // ... and everyone's; the other buffer's readers are done
+    if (t + t_step < t_hi) copy_tile(t + t_step, buf ^ 1);
+    if (!wave_live) continue;
+    const unsigned char *tb = ldsb + buf * TILEB;
+    const int64_t t_row0 = (int64_t)t * CT;
+#pragma unroll
+    for (int b = 0; b < NB; b += 2) {
+      if (b > 0 || pend >= 0) {
+        mma_half(acc0, tb, b, [&](const int kk) {
+#pragma unroll
+          for (int j = 0; j < SPK; ++j) scan(h1, acc1, kk * SPK + j);
+        });
+        finish(h1, acc1, b > 0 ? t_row0 + 32 * (b - 1) : pend);
+      } else {
+        mma_half(acc0, tb, b, [&](const int) {});
+      }
+      mma_half(acc1, tb, b + 1, [&](const int kk) {
+#pragma unroll
+        for (int j = 0; j < SPK; ++j) scan(h0, acc0, kk * SPK + j);
+      });
+      finish(h0, acc0, t_row0 + 32 * b);
+    }
+    pend = t_row0 + 32 * (NB - 1);
+  }
+  if (wave_live && pend >= 0) {
+#pragma unroll
+    for (int st = 0; st < 16; ++st) scan(h1, acc1, st);
+    finish(h1, acc1, pend);
   }
   // positive elements seen by this wave -> one atomic
   unsigned long long tot = n_pos;
@@ -326,8 +372,9 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // k_head_gemv: the same filter for a query batch too small to fill 32-row MFMA blocks (single-vector messages of the
-// latency path, benchmark/LoadGenerator.scala:58-74): HBM-bound sweep of W, 8 lanes per candidate row, the query
-// vectors (<= 8 per launch group) in LDS as fp32.
+// latency path, benchmark/LoadGenerator.scala:58-74): HBM-bound sweep of W.  One wave per candidate tile, lane = row:
+// every load is one contiguous KiB (a chunk of the tile), every lane keeps its own row's dot products with the (<= 8
+// per pass) query vectors, which sit in LDS as fp32.
 struct HeadGemvArgs {
   const uint16_t *Wq;
   const uint16_t *Wc;
@@ -350,9 +397,9 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
   __shared__ float qv[kGemvQ][256];
   __shared__ unsigned long long npos;
   const int tid = threadIdx.x, ln = tid % kWave;
-  const int j = ln & 7;  // this lane's 16-B chunk inside a group of 8 lanes
   const int64_t qs0 = a.q_slot_base >= 0 ? a.q_slot_base : 0;
   const int cpr = a.kh / 8;
+  const int64_t n_tiles = (a.n_rows + kHeadCTile - 1) / kHeadCTile;
   if (tid == 0) npos = 0;
   unsigned long long my_pos = 0;
   for (int q0 = 0; q0 < a.nq; q0 += kGemvQ) {
@@ -360,42 +407,33 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
     __syncthreads();
     for (int i = tid; i < nqq * a.kh; i += blockDim.x) {
       const int qq = i / a.kh, k = i % a.kh;
-      const uint16_t b = a.Wq[(qs0 + q0 + qq) * a.kh + k];
+      const uint16_t b = a.Wq[head_chunk_off(qs0 + q0 + qq, k >> 3, a.kh) + (k & 7)];
       qv[qq][k] = __uint_as_float((uint32_t)b << 16);
     }
     __syncthreads();
-    // 8 candidate rows per wave step, 4 waves per workgroup, grid-stride over the rows
-    for (int64_t c0 = ((int64_t)blockIdx.x * 4 + tid / kWave) * 8; c0 < a.n_rows; c0 += (int64_t)gridDim.x * 32) {
-      const int64_t c = c0 + (ln >> 3);
+    for (int64_t t = (int64_t)blockIdx.x * 4 + tid / kWave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+      const int64_t c = t * kHeadCTile + ln;
       float s[kGemvQ];
 #pragma unroll
       for (int qq = 0; qq < kGemvQ; ++qq) s[qq] = 0.f;
-      if (c < a.n_rows) {
-        const uint4 *rowp = reinterpret_cast<const uint4 *>(a.Wc + c * a.kh);
-        for (int ch = j; ch < cpr; ch += 8) {
-          const uint4 v = rowp[ch];
-          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      const uint4 *tp = reinterpret_cast<const uint4 *>(a.Wc) + t * (cpr * kHeadCTile) + ln;
+      for (int ch = 0; ch < cpr; ++ch) {
+        const uint4 v = tp[ch * kHeadCTile];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
 #pragma unroll
-            for (int qq = 0; qq < kGemvQ; ++qq)
-              if (qq < nqq) s[qq] += lo * qv[qq][ch * 8 + 2 * e] + hi * qv[qq][ch * 8 + 2 * e + 1];
-          }
+          for (int qq = 0; qq < kGemvQ; ++qq)
+            if (qq < nqq) s[qq] += lo * qv[qq][ch * 8 + 2 * e] + hi * qv[qq][ch * 8 + 2 * e + 1];
         }
       }
 #pragma unroll
       for (int qq = 0; qq < kGemvQ; ++qq) {
-        s[qq] += __shfl_xor(s[qq], 1);
-        s[qq] += __shfl_xor(s[qq], 2);
-        s[qq] += __shfl_xor(s[qq], 4);
-      }
-#pragma unroll
-      for (int qq = 0; qq < kGemvQ; ++qq) {
         if (qq >= nqq) break;
-        const bool lead = j == 0 && c < a.n_rows;
-        if (lead && s[qq] > 0.f) my_pos++;
-        bool ok = lead && s[qq] >= a.thr;
+        const bool in = c < a.n_rows;
+        if (in && s[qq] > 0.f) my_pos++;
+        bool ok = in && s[qq] >= a.thr;
         if (ok) ok = a.q_ext[q0 + qq] != a.c_ext[c];
         const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
         if (ok && o < a.res_cap) {

@@ -158,6 +158,7 @@ struct apss_handle {
   DevBuf<float> uq_s;
   int64_t head_nonempty = 0, last_batch_head_nonempty = 0;
   int64_t idx_tail_valid = 0;         // entries of idx_tail that are filled in
+  double head_sample_frac = 0.0;      // fraction of sampled pairs the dense filter passed when the policy last looked
   hipEvent_t ev2 = nullptr, ev3 = nullptr;
   // stats
   apss_stats st{};
@@ -424,7 +425,10 @@ int32_t ensure_exact_index(apss_handle *h) {
 // ---- dense-head block (apss_head.hpp) ----
 constexpr int64_t kHeadMinRows = 16384;  // below this a join is over before a GEMM pays for its set-up
 constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse filter (measured, C3)
-constexpr double kHeadDenseRate = 6.0e14;   // flop / s the head contraction sustains (measured, profiles/r02_head_gemm.md)
+// seconds per (query, candidate) element of the head contraction, block width 64 / 128 / 256 (measured on random rows,
+// profiles/r02_head_gemm.md: 1.65 PFLOP/s at 256; narrower blocks are bound by the epilogue's scan, not by the MFMAs)
+constexpr double kHeadDenseCost[3] = {1.5e-13, 1.9e-13, 3.1e-13};
+constexpr double kHeadSurvivorCost = 1.0e-8;  // seconds per element the dense filter passes on (report + de-dup + exact re-score)
 
 inline bool head_allowed(const apss_handle *h) {
   return h->use_coarse && !h->sharded && h->cfg.head_terms >= 0 && h->cfg.theta > 0.0 && !h->head_blocked && h->nonneg;
@@ -434,13 +438,13 @@ inline bool head_allowed(const apss_handle *h) {
 int32_t head_pack_store(apss_handle *h, int64_t row0) {
   const int64_t kh = h->head_k;
   const int64_t rows_pad = ceil_div(h->n_rows, kHeadQBlock) * kHeadQBlock + kHeadCTile;
-  APSS_TRY(ensure(h, h->W, (size_t)(rows_pad * kh), (size_t)(row0 * kh)));
+  APSS_TRY(ensure(h, h->W, (size_t)(rows_pad * kh), (size_t)(ceil_div(row0, kHeadCTile) * kHeadCTile * kh)));  // (tiled: whole tiles)
   APSS_TRY(ensure(h, h->sub, (size_t)h->n_rows, (size_t)row0));
   APSS_TRY(ensure(h, h->idx_tail, (size_t)std::max<int64_t>(h->nnz, 1), (size_t)(row0 ? h->idx_tail_valid : 0)));
   h->idx_tail_valid = h->nnz;
   APSS_TRY(ensure(h, h->head_ctr, 4));
   HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
-  if (h->n_rows > row0) {
+  {
     HeadPackArgs a{};
     a.rowptr = h->rowptr.p;
     a.idx = h->idx.p;
@@ -451,12 +455,12 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
     a.kh = (int32_t)kh;
     a.W = h->W.p;
     a.w_row0 = row0;
+    a.w_pad = rows_pad;  // the rows past the last one are zero rows: a GEMM tile or query block may read them
     a.ratio_t = h->sub.p;
     a.idx_tail = h->idx_tail.p;
     a.head_nonempty = reinterpret_cast<unsigned int *>(h->head_ctr.p);
-    hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(h->n_rows - row0, 4)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_head_pack, dim3((unsigned)(ceil_div(rows_pad, 8) - row0 / 8)), dim3(512), 0, h->stream, a);
   }
-  hipLaunchKernelGGL(k_head_zero_rows, dim3(64), dim3(256), 0, h->stream, h->W.p, h->n_rows, rows_pad, (int32_t)kh);
   HIPCHK(h, hipGetLastError());
   unsigned int nz = 0;
   HIPCHK(h, hipMemcpyAsync(&nz, h->head_ctr.p, sizeof(nz), hipMemcpyDeviceToHost, h->stream));
@@ -464,6 +468,53 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
   if (row0 == 0) h->head_nonempty = 0;
   h->head_nonempty += nz;
   h->last_batch_head_nonempty = nz;
+  return APSS_OK;
+}
+
+int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_base, const uint16_t *Wq, int64_t wq_rows,
+                 float thr, int64_t n_cand);
+
+// How selective is the dense filter on THIS data: the block's first rows (at most 8192) against its first 512 as queries,
+// counted, not stored.  Returns the fraction of (q, c != q) elements at or above the threshold.  (Rows arrive in no
+// particular order in the reference's stream -- ShardRegion routing is random, CommonUtils.scala:28-40 -- so a prefix is a
+// sample.)
+int32_t head_sample_selectivity(apss_handle *h, double *frac) {
+  *frac = 0.0;
+  const int64_t kh = h->head_k;
+  const int64_t S = std::min<int64_t>(h->n_rows, 8192), Q = std::min<int64_t>(S, 512);
+  const int64_t rows_pad = ceil_div(h->n_rows, kHeadQBlock) * kHeadQBlock + kHeadCTile;
+  APSS_TRY(ensure(h, h->W, (size_t)(rows_pad * kh), 0));
+  APSS_TRY(ensure(h, h->sub, (size_t)h->n_rows, 0));
+  APSS_TRY(ensure(h, h->head_ctr, 4));
+  APSS_TRY(ensure(h, h->counters, kCtrCount));
+  HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
+  HeadPackArgs p{};
+  p.rowptr = h->rowptr.p;
+  p.idx = h->idx.p;
+  p.val = h->val.p;
+  p.row0 = 0;
+  p.row1 = S;
+  p.head_pos = h->head_pos.p;
+  p.kh = (int32_t)kh;
+  p.W = h->W.p;
+  p.w_row0 = 0;
+  p.w_pad = ceil_div(S, kHeadQBlock) * kHeadQBlock;
+  p.ratio_t = h->sub.p;
+  p.idx_tail = nullptr;
+  p.head_nonempty = nullptr;
+  hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(p.w_pad, 8)), dim3(512), 0, h->stream, p);
+  HIPCHK(h, hipGetLastError());
+  ProbeArgs a{};
+  a.q_ext = h->ext.p;
+  a.res_cap = 0;  // count only
+  a.counters = h->head_ctr.p + 2;
+  const double bound = (double)h->store_max_norm2 * 1.0001 + 1e-6;  // |q||c| <= the largest squared row norm
+  APSS_TRY(run_head(h, a, Q, -1, h->W.p, p.w_pad, (float)(h->cfg.theta - 0.0080 * bound - 1e-5), S));
+  unsigned long long c[4];
+  HIPCHK(h, hipMemcpyAsync(c, h->head_ctr.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const double pairs = (double)Q * (double)S - (double)Q;
+  *frac = pairs > 0 ? (double)c[2] / pairs : 0.0;
   return APSS_OK;
 }
 
@@ -491,39 +542,57 @@ int32_t choose_head(apss_handle *h, bool *changed) {
   std::partial_sort(order.begin(), order.begin() + (ptrdiff_t)top, order.end(),
                     [&](int32_t x, int32_t y) { return df[(size_t)x] != df[(size_t)y] ? df[(size_t)x] > df[(size_t)y] : x < y; });
   int32_t k = 0;
+  double best_gain = 0.0;  // seconds per N^2 pairs the chosen block is expected to save
   if (h->cfg.head_terms > 0) {
     k = h->cfg.head_terms <= 64 ? 64 : (h->cfg.head_terms <= 128 ? 128 : 256);
   } else if (n >= kHeadMinRows) {
     double best = 0.0, s2 = 0.0;
     size_t i = 0;
+    int ki = 0;
     for (int32_t kk : {64, 128, 256}) {
       for (; i < std::min<size_t>(top, (size_t)kk); ++i) {
         const double f = (double)df[(size_t)order[i]] / (double)sampled;
         s2 += f * f;
       }
-      const double save = s2 / kHeadSparseRate, cost = (double)kk / kHeadDenseRate;  // per N^2 (stored batch: 2 * K * N^2 / 2 flop)
+      // per N^2 pairs of a stored batch: df_t^2 = f_t^2 N^2 visits saved; half of the product computed (symmetric)
+      const double save = s2 / kHeadSparseRate, cost = 0.5 * kHeadDenseCost[ki++];
       if (save >= 1.5 * cost && save - cost > best) {
         best = save - cost;
         k = kk;
       }
     }
+    best_gain = best;
   }
   if (k > dim) k = 0;
   std::vector<int32_t> terms;
   for (size_t i = 0; i < std::min<size_t>(top, (size_t)k); ++i)
     if (df[(size_t)order[i]] > 0) terms.push_back(order[i]);
   if (terms.empty()) k = 0;
-  *changed = k != h->head_k || terms != h->head_terms;
-  if (!*changed) return APSS_OK;
+  const int32_t old_k = h->head_k;
+  const std::vector<int32_t> old_terms = h->head_terms;
+  const bool differs = k != old_k || terms != old_terms;
   h->head_k = k;
   h->head_terms = terms;
-  if (k) {
+  if (k && differs) {
     std::vector<int32_t> pos((size_t)dim, -1);
     for (size_t i = 0; i < terms.size(); ++i) pos[(size_t)terms[i]] = (int32_t)i;
     APSS_TRY(ensure(h, h->head_pos, (size_t)dim));
     HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));  // `pos` goes out of scope
   }
+  if (k && differs && h->cfg.head_terms == 0) {  // (a block that is already in use has passed this test)
+    // the visit count says yes; now the other side of the ledger: every element the dense filter passes is reported,
+    // de-duplicated and re-scored (measured: ~10 ns each).  At a low threshold on strongly skewed data that can be a
+    // fraction of a percent of N^2 -- more than the posting visits saved (C2: theta = 0.5).  Measure it on a sample.
+    double frac = 0.0;
+    APSS_TRY(head_sample_selectivity(h, &frac));
+    h->head_sample_frac = frac;
+    if (frac * kHeadSurvivorCost > 0.5 * best_gain) {
+      h->head_k = 0;
+      h->head_terms.clear();
+    }
+  }
+  *changed = h->head_k != old_k || h->head_terms != old_terms;
   return APSS_OK;
 }
 
@@ -631,13 +700,13 @@ int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
 
 // ---- dense-head filter of one query batch (apss_head.hpp): appends its candidates to the sparse filter's list ----
 int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_base, const uint16_t *Wq, int64_t wq_rows,
-                 float thr) {
+                 float thr, int64_t n_cand) {
   const int kh = h->head_k;
   if (nq <= 2 * kGemvQ) {
     HeadGemvArgs g{};
     g.Wq = Wq;
     g.Wc = h->W.p;
-    g.n_rows = h->n_rows;
+    g.n_rows = n_cand;
     g.q_slot_base = q_slot_base;
     g.nq = (int32_t)nq;
     g.kh = kh;
@@ -650,30 +719,30 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
     g.res_cap = a.res_cap;
     g.counters = a.counters;
     g.head_pairs = h->head_ctr.p + 1;
-    const int64_t blocks = std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div(h->n_rows, 32)));
+    const int64_t blocks = std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div(n_cand, 256)));
     hipLaunchKernelGGL(k_head_gemv, dim3((unsigned)blocks), dim3(256), 0, h->stream, g);
     HIPCHK(h, hipGetLastError());
-    h->st.head_flops = 2.0 * kh * (double)nq * (double)h->n_rows;
+    h->st.head_flops = 2.0 * kh * (double)nq * (double)n_cand;
     return APSS_OK;
   }
   HeadGemmArgs g{};
   g.Wq = Wq;
   g.Wc = h->W.p;
   g.wq_rows = wq_rows;
-  g.n_rows = h->n_rows;
+  g.n_rows = n_cand;
   g.q_slot_base = q_slot_base;
   g.nq = (int32_t)nq;
   const int64_t qs0 = q_slot_base >= 0 ? q_slot_base : 0;
   g.qblock0 = qs0 / kHeadQBlock * kHeadQBlock;
   g.n_qblocks = (int32_t)(ceil_div(qs0 + nq, kHeadQBlock) - qs0 / kHeadQBlock);
-  g.n_ctiles = (int32_t)ceil_div(h->n_rows, kHeadCTile);
+  const int64_t ct = head_tile_rows(kh);
+  g.n_ctiles = (int32_t)ceil_div(n_cand, ct);
   // candidate panels: enough workgroups to fill the chip several times over, a multiple of 8 (= XCDs) so that every
   // workgroup of an XCD streams panels of one residue class, and long enough to amortise the A-fragment load
   int64_t panels = 8;
   while (panels * g.n_qblocks < 2048 && g.n_ctiles / (2 * panels) >= 32) panels *= 2;
   panels = std::max<int64_t>(1, std::min<int64_t>(panels, g.n_ctiles));
   g.n_panels = (int32_t)panels;
-  g.tiles_per_panel = (int32_t)ceil_div(g.n_ctiles, panels);
   g.q_ext = a.q_ext;
   g.c_ext = h->ext.p;
   g.thr = thr;
@@ -691,10 +760,10 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
   // multiplied elements: every (query block, candidate tile) the grid does not skip, at MFMA granularity
   double tiles = 0;
   for (int64_t b = 0; b < g.n_qblocks; ++b) {
-    const int64_t hi = q_slot_base >= 0 ? std::min<int64_t>(g.n_ctiles, (g.qblock0 + (b + 1) * kHeadQBlock) / kHeadCTile) : g.n_ctiles;
+    const int64_t hi = q_slot_base >= 0 ? std::min<int64_t>(g.n_ctiles, (g.qblock0 + (b + 1) * kHeadQBlock) / ct) : g.n_ctiles;
     tiles += (double)hi;
   }
-  h->st.head_flops = 2.0 * kh * tiles * (double)kHeadCTile * (double)kHeadQBlock;
+  h->st.head_flops = 2.0 * kh * tiles * (double)ct * (double)kHeadQBlock;
   return APSS_OK;
 }
 
@@ -834,9 +903,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     const double nw = cxv.block / kWave;
     const double seg = (double)h->cx.cb * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;  // postings per (tile, term)
     double q_terms = (double)q_nnz_end / (double)nq;
-    if (shard_rule) q_terms += 2.0 * std::sqrt(q_terms);  // a shard holds a binomial share of each query's terms
-    const double wave_chunks = std::ceil(q_terms / nw - 1e-9) * std::max(1.0, seg / 16.0 + 0.5);
-    int u = (int)std::ceil(wave_chunks * 1.05 / 8.0);
+    // a shard holds a binomial share of each query's terms; a window that overflows costs a whole-tile clear, so the
+    // shard-rule launches size it for the upper end (3 sigma) and for segments one chunk longer than their mean
+    const double t_hi = shard_rule ? q_terms + 3.0 * std::sqrt(q_terms) : q_terms;
+    const double wave_chunks = std::ceil(t_hi / nw - 1e-9) * std::max(1.0, seg / 16.0 + (shard_rule ? 1.0 : 0.5));
+    int u = (int)std::ceil(wave_chunks * (shard_rule ? 1.0 : 1.05) / 8.0);
     if (cxv.block == 1024) u = (q_terms / nw) * std::max(1.0, seg / 16.0 + 0.5) <= 17.0 && !dbg.big_u5 ? 3 : 5;
     else u = std::max(2, std::min(5, u));
     if (cxv.vrows || cxv.sgn) u = cxv.block == 1024 ? u : 5;
@@ -958,7 +1029,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
       HIPCHK(h, hipEventRecord(h->ev2, h->stream));
       const bool stored = q_slot_base >= 0;
-      APSS_TRY(run_head(h, a, nq, q_slot_base, stored ? h->W.p : h->q_W.p, stored ? (int64_t)(h->W.cap / h->head_k) : nq, head_thr));
+      APSS_TRY(run_head(h, a, nq, q_slot_base, stored ? h->W.p : h->q_W.p, stored ? (int64_t)(h->W.cap / h->head_k) : ceil_div(nq, kHeadCTile) * kHeadCTile, head_thr, h->n_rows));
       HIPCHK(h, hipEventRecord(h->ev3, h->stream));
       HIPCHK(h, hipMemcpyAsync(head_c, h->head_ctr.p, sizeof(head_c), hipMemcpyDeviceToHost, h->stream));
     }
@@ -1135,7 +1206,8 @@ int32_t query_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_
   APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, false, &kept_rows, &kept_nnz));
   if (h->head_k && kept_rows > 0) {
     // the batch's rows of the dense-head block and its tail ratios (the store's were packed when it was indexed)
-    APSS_TRY(ensure(h, h->q_W, (size_t)(kept_rows * h->head_k)));
+    const int64_t q_pad = ceil_div(kept_rows, kHeadCTile) * kHeadCTile;
+    APSS_TRY(ensure(h, h->q_W, (size_t)(q_pad * h->head_k)));
     APSS_TRY(ensure(h, h->q_sub, (size_t)kept_rows));
     HeadPackArgs a{};
     a.rowptr = h->q_rowptr.p;
@@ -1147,10 +1219,11 @@ int32_t query_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_
     a.kh = h->head_k;
     a.W = h->q_W.p;
     a.w_row0 = 0;
+    a.w_pad = q_pad;
     a.ratio_t = h->q_sub.p;
     a.idx_tail = nullptr;
     a.head_nonempty = nullptr;
-    hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(kept_rows, 4)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(q_pad, 8)), dim3(512), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
   }
   return probe(h, kept_rows, h->q_rowptr.p, h->q_idx.p, h->q_val.p, h->q_ext.p, h->q_sub.p, -1, h->q_max_nnz, h->q_max_norm2,

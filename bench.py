@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", help="c2 | c3 | c3z | c3z1 | c5s | c5 | c5z (c3 is the metric's)")
-    ap.add_argument("--n", type=int, default=None, help="override the number of vectors (debug)")
+    ap.add_argument("--rows", "--n", dest="n", type=int, default=None, help="override the number of vectors (debug); "
+                    "spell it --rows under torch.distributed.run, whose own parser claims every prefix of its options")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--head-terms", type=int, default=0, help="dense-head block: 0 auto, -1 never, 64 | 128 | 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -13,7 +13,7 @@ DRIVER_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_s
 
 
 def _one_line(out):
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]  # (gloo rehearsals print connection chatter to stdout)
     assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
     return json.loads(lines[0])
 
@@ -75,7 +75,7 @@ def test_bench_two_ranks_report_both_layouts():
     term-range-sharded layout with its all-gather + all-reduce, the candidate-range layout rides along, same result"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "40000",
+                          "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "40000",
                           "--steps", "2", "--warmup", "1", "--backend", "gloo", "--cpu-seconds", "1"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
