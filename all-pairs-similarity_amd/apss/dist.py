@@ -52,17 +52,22 @@ class HipShardEngine:
         # run on torch's stream: the tensors handed to the library are produced by torch kernels on that stream
         self.ix.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
-    def load(self, rp, idx, val, row_range=None):
+    def load(self, rp, idx, val, row_range=None, device_arrays=None):
+        """the batch as host CSR (numpy), or already resident: device_arrays = (rowptr int64, idx int32, val fp32) on
+        this engine's GPU (several shard engines of one process then share one copy)"""
         dev = self.device
-        self.n = len(rp) - 1
+        if device_arrays is not None:
+            self.d_rp, self.d_idx, self.d_val = device_arrays
+        else:
+            self.d_rp = torch.from_numpy(rp).to(dev)
+            self.d_idx = torch.from_numpy(idx).to(dev)
+            self.d_val = torch.from_numpy(val.astype(np.float32)).to(dev)
+        self.n = self.d_rp.numel() - 1
         self.r0, self.r1 = (0, self.n) if row_range is None else row_range
-        self.d_rp = torch.from_numpy(rp).to(dev)
-        self.d_idx = torch.from_numpy(idx).to(dev)
-        self.d_val = torch.from_numpy(val.astype(np.float32)).to(dev)
         self.d_ids = torch.arange(self.n, dtype=torch.int64, device=dev)
         self.whole = (self.r0, self.r1) == (0, self.n)
         if not self.whole:  # the candidate rows of this shard as their own CSR batch
-            e0, e1 = int(rp[self.r0]), int(rp[self.r1])
+            e0, e1 = int(self.d_rp[self.r0].item()), int(self.d_rp[self.r1].item())
             self.s_rp = (self.d_rp[self.r0:self.r1 + 1] - e0).contiguous()
             self.s_idx = self.d_idx[e0:e1].contiguous()
             self.s_val = self.d_val[e0:e1].contiguous()

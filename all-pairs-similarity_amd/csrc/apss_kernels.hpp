@@ -1246,9 +1246,16 @@ __global__ void k_vrow_fill(const int64_t *rowptr, int64_t n, int part, const in
 // candidates per 32-bit word), so a tile holds 32768 candidates in 64 KB: half the (query, tile) rounds of the exact
 // kernel at two workgroups per CU, and about half the memory-side bytes per posting visit.
 // It reports every pair whose coarse sum reaches  floor(theta*S*(1 - 2^-11 - 1e-6)) - 2  (S = cx_scale).
-// No true pair is lost: fp16 rounds a weight by at most 2^-11 relative, each product is rounded UP to an integer
-// (floor(x) + 1), integer sums are exact, so  coarse >= S*true*(1 - 2^-11).  The survivors (a few per thousand more
-// than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.  A sum exceeds S*q.c by at
+// No true pair is lost.  A stored weight c_i becomes fp16: round-to-nearest errs by at most 2^-11 RELATIVE while the
+// value is a normal fp16 (>= 2^-14) and by at most 2^-25 ABSOLUTE below that (subnormals; a weight under fp16's range is
+// clamped UP to the smallest subnormal by pack_coarse), so  fp16(c_i) >= c_i (1 - 2^-11) - 2^-25.  Each product
+// S q_i fp16(c_i) is rounded UP to an integer (floor(x) + 1) and integer sums are exact, hence
+//     coarse >= S * true * (1 - 2^-11)  -  S * 2^-25 * sum_i q_i .
+// The first term is the factor in the threshold.  The second is at most S 2^-25 sqrt(nnz_q) |q| units: 0.05 units for
+// a unit-norm query of 2,247 terms at S = 2^15, and never more for un-normalised rows (S |q||c| < 2^16 caps S |q|);
+// the fp32 rounding of the scaled query weight S q_i is another ~2^-9 units.  Both sit inside the 2 units subtracted
+// from the threshold (tests/test_gpu_soundness.py attacks exactly these corners).  The survivors (a few per thousand
+// more than the true pairs) are re-scored from the fp32 store by k_rescore and pruned at theta.  A sum exceeds S*q.c by at
 // most one unit per shared term; the host picks S so that S*|q||c| + min(nnz_q, nnz_c) stays below 2^16 (no carry).
 // __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
 // sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.

@@ -237,7 +237,7 @@ int64_t oracle_worker_index_data(oracle_worker *w, int64_t n, const int64_t *ids
   }
 
   /* ---- buildInvertedIndex (IWA:61-71): the whole batch is indexed before any query runs ---- */
-  if (!query_only) {
+  if (query_only != 1) {
     for (int64_t i = 0; i < n; ++i) {
       /* vectorsStore += candidateVector; currentIdx = vectorsStore.length - 1 */
       int32_t slot = (int32_t)w->ids.len;
@@ -255,6 +255,13 @@ int64_t oracle_worker_index_data(oracle_worker *w, int64_t n, const int64_t *ids
         for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) VEC_PUSH(&w->postings[indices[k]], int32_t, slot);
       }
     }
+  }
+
+  if (query_only == 2) { /* build only: the warm-up of a latency run indexes the data set without reading answers */
+    if (out_q) *out_q = NULL;
+    if (out_c) *out_c = NULL;
+    if (out_sim) *out_sim = NULL;
+    return 0;
   }
 
   /* ---- querySimilarItems (IWA:74-111) ---- */

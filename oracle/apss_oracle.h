@@ -47,7 +47,8 @@ int64_t oracle_worker_size(const oracle_worker *w);
 
 /*
  * The `case IndexData(vectors)` handler (IWA:123-137): buildInvertedIndex(batch) unless
- * `query_only` (stopUpdateIndex, IWA:125-127), then querySimilarItems(batch).
+ * `query_only` == 1 (stopUpdateIndex, IWA:125-127), then querySimilarItems(batch); `query_only` == 2 builds only (no
+ * answers are computed: the warm-up phase of a latency run).
  *
  * Batch layout: n wrappers; wrapper i has the FULL vector rowptr[i]..rowptr[i+1] (indices strictly
  * increasing, < dim) and the LOCAL dims lptr[i]..lptr[i+1] (the wrapper's `indices: Set[Int]`, in

@@ -119,7 +119,7 @@ class Worker:
     def __len__(self):
         return lib().oracle_worker_size(self._h)
 
-    def index_data(self, ids, rowptr, indices, values, local=None, query_only=False):
+    def index_data(self, ids, rowptr, indices, values, local=None, query_only=False, build_only=False):
         """`case IndexData(vectors)`.  local = (lptr, ldims) or None (all dims, ascending).
         Returns (q_ids, c_ids, sims) sorted by (q, c)."""
         ids = np.ascontiguousarray(ids, dtype=np.int64)
@@ -139,7 +139,7 @@ class Worker:
         oq, oc, os_ = _i64p(), _i64p(), _f64p()
         ids_arr = ids if n else np.zeros(1, np.int64)
         m = lib().oracle_worker_index_data(self._h, n, _p(ids_arr, _i64p), _p(rowptr, _i64p), _p(indices, _i32p),
-                                           _p(values, _f64p), lptr_p, ld_p, int(query_only),
+                                           _p(values, _f64p), lptr_p, ld_p, 2 if build_only else int(query_only),
                                            C.byref(oq), C.byref(oc), C.byref(os_))
         if m == -3:
             raise KeyError("NoSuchElementException: unseen dim on a frozen index (IWA:104)")

@@ -116,3 +116,21 @@ def test_two_shard_counterexample_of_the_unit_norm_rule(oracle):
         e.load(rp, idx, val)
     q, c, s, _ = join_shards_local(engines, 2, theta)
     assert_same_pairs(to_map(q, c, s), want, theta)
+
+
+def test_c4_full_size_eight_term_shards_on_one_gpu():
+    """BASELINE.json configs[3] (C3's N = 1M, dim = 100k, nnz = 100, theta = 0.8, index term-sharded 8 ways) at FULL size on
+    one GPU: the eight term-range shard handles are built one after another, joined with join_shards_local (the
+    in-process twin of the RCCL exchange), and the result is checked by the oracle-free stratified property: every
+    planted pair, nothing else, every score exact, posting visits of the shards adding up to sum df^2"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fullsize_stratified", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "fullsize_stratified.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run_term_shards(1_000_000, 100_000, 100, 0.8, 8, seed=20242)
+    assert out["missing"] == 0 and out["unexpected"] == 0 and out["planted_pairs_required"] > 50_000
+    assert len(out["probe_ms_per_shard"]) == 8 and out["max_abs_score_error"] <= 1e-5
+    # the exchange stays small: a shard's candidate list is of the order of the true pairs, not of the touched pairs
+    assert max(out["candidates_per_shard"]) < 4 * out["result_pairs"]
