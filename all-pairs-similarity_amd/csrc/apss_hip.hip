@@ -45,6 +45,7 @@ struct DebugCfg {
   int window = 0;              // window=U       register-window steps of the 512-thread filter kernel (2..5)
   int chunks = 0;              // chunks=N       query chunks per tile (grid shape)
   int tiles_per_launch = 0;    // tiles_per_launch=N
+  bool no_tail = false;        // no_tail        every insert extends the tile index at once (no tail of waiting rows)
 };
 
 DebugCfg parse_debug_env() {
@@ -72,6 +73,7 @@ DebugCfg parse_debug_env() {
     else if (key == "window") d.window = val;
     else if (key == "chunks") d.chunks = val;
     else if (key == "tiles_per_launch") d.tiles_per_launch = val;
+    else if (key == "no_tail") d.no_tail = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -97,6 +99,7 @@ struct apss_handle {
 
   // store (CSR) -- vectorsStore, IWA:22
   int64_t n_rows = 0, nnz = 0;
+  int64_t idx_rows = 0;  // rows [0, idx_rows) are in the tile index (and in W); rows [idx_rows, n_rows) wait in the tail (probe: k_tail_score)
   DevBuf<int64_t> rowptr, ext;
   DevBuf<int32_t> idx;
   DevBuf<uint32_t> erow;  // store row of every entry
@@ -337,7 +340,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
 int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   const int64_t cb = ix.cb;
   const int64_t tile0 = row0 / cb;
-  const int64_t n_tiles = ceil_div(h->n_rows, cb);
+  const int64_t n_tiles = ceil_div(h->idx_rows, cb);
   const int64_t stride = (int64_t)h->cfg.dim;
   ix.n_tiles = n_tiles;
   if (n_tiles == tile0) return APSS_OK;
@@ -363,7 +366,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.idx = h->head_k ? h->idx_tail.p : h->idx.p;  // dense-head entries are masked out of the inverted index
   b.val = h->val.p;
   b.row0 = r0;
-  b.row1 = h->n_rows;
+  b.row1 = h->idx_rows;
   b.cb = (int32_t)cb;
   b.dim = h->cfg.dim;
   b.tile_seg = ix.seg.p;
@@ -373,7 +376,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.erow = h->erow.p;
   b.coarse_shift = ix.coarse && ix.cb <= 32768 ? 1 : 0;  // must agree with k_probe_coarse's SLOT2 (the 512-thread kernels)
   const int threads = 256;
-  const int64_t blocks = ceil_div((h->n_rows - r0) * kWave, threads);
+  const int64_t blocks = ceil_div((h->idx_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   const dim3 lds_grid((unsigned)((n_tiles - tile0) * n_ranges));
   if (lds_build) hipLaunchKernelGGL(k_tile_hist_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
@@ -401,7 +404,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   else hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
   if (scaled)
     hipLaunchKernelGGL(k_tile_min_sub, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream,
-                       (const float *)h->sub.p, h->n_rows, (int32_t)cb, tmin.p, tile0);
+                       (const float *)h->sub.p, h->idx_rows, (int32_t)cb, tmin.p, tile0);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipEventSynchronize(h->ev1));
@@ -414,15 +417,18 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
 // Which renderings of the index a handle keeps: the coarse one (two-pass speed path) is built at insert time when the
 // handle may use it; the exact one is built at insert time otherwise, or lazily by the first probe that needs it.
 int32_t ensure_exact_index(apss_handle *h) {
-  if (h->ex_built_rows < h->n_rows || h->ex.n_tiles == 0) {
-    APSS_TRY(build_tiles(h, h->ex, std::min(h->ex_built_rows, h->n_rows)));
-    h->ex_built_rows = h->n_rows;
+  if (h->ex_built_rows < h->idx_rows || h->ex.n_tiles == 0) {
+    APSS_TRY(build_tiles(h, h->ex, std::min(h->ex_built_rows, h->idx_rows)));
+    h->ex_built_rows = h->idx_rows;
     h->st.build_ms += h->ex.build_ms;
   }
   return APSS_OK;
 }
 
 // ---- dense-head block (apss_head.hpp) ----
+constexpr int64_t kTailMaxRows = 4096;   // rows that may wait outside the tile index (scored pair by pair by k_tail_score)
+constexpr int64_t kTailMaxBatch = 256;   // a batch larger than this extends the index right away
+constexpr int64_t kTailMaxPairs = 1 << 22;  // (queries x tail rows) a probe scores directly; beyond it the tail is folded in first
 constexpr int64_t kHeadMinRows = 16384;  // below this a join is over before a GEMM pays for its set-up
 constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse filter (measured, C3)
 // seconds per (query, candidate) element of the head contraction, block width 64 / 128 / 256 (measured on random rows,
@@ -437,9 +443,9 @@ inline bool head_allowed(const apss_handle *h) {
 // W rows, tail ratios and the masked term array for store rows [row0, n_rows)
 int32_t head_pack_store(apss_handle *h, int64_t row0) {
   const int64_t kh = h->head_k;
-  const int64_t rows_pad = ceil_div(h->n_rows, kHeadQBlock) * kHeadQBlock + kHeadCTile;
+  const int64_t rows_pad = ceil_div(h->idx_rows, kHeadQBlock) * kHeadQBlock + kHeadCTile;
   APSS_TRY(ensure(h, h->W, (size_t)(rows_pad * kh), (size_t)(ceil_div(row0, kHeadCTile) * kHeadCTile * kh)));  // (tiled: whole tiles)
-  APSS_TRY(ensure(h, h->sub, (size_t)h->n_rows, (size_t)row0));
+  APSS_TRY(ensure(h, h->sub, (size_t)h->idx_rows, (size_t)row0));
   APSS_TRY(ensure(h, h->idx_tail, (size_t)std::max<int64_t>(h->nnz, 1), (size_t)(row0 ? h->idx_tail_valid : 0)));
   h->idx_tail_valid = h->nnz;
   APSS_TRY(ensure(h, h->head_ctr, 4));
@@ -450,7 +456,7 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
     a.idx = h->idx.p;
     a.val = h->val.p;
     a.row0 = row0;
-    a.row1 = h->n_rows;
+    a.row1 = h->idx_rows;
     a.head_pos = h->head_pos.p;
     a.kh = (int32_t)kh;
     a.W = h->W.p;
@@ -481,10 +487,10 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
 int32_t head_sample_selectivity(apss_handle *h, double *frac) {
   *frac = 0.0;
   const int64_t kh = h->head_k;
-  const int64_t S = std::min<int64_t>(h->n_rows, 8192), Q = std::min<int64_t>(S, 512);
-  const int64_t rows_pad = ceil_div(h->n_rows, kHeadQBlock) * kHeadQBlock + kHeadCTile;
+  const int64_t S = std::min<int64_t>(h->idx_rows, 8192), Q = std::min<int64_t>(S, 512);
+  const int64_t rows_pad = ceil_div(h->idx_rows, kHeadQBlock) * kHeadQBlock + kHeadCTile;
   APSS_TRY(ensure(h, h->W, (size_t)(rows_pad * kh), 0));
-  APSS_TRY(ensure(h, h->sub, (size_t)h->n_rows, 0));
+  APSS_TRY(ensure(h, h->sub, (size_t)h->idx_rows, 0));
   APSS_TRY(ensure(h, h->head_ctr, 4));
   APSS_TRY(ensure(h, h->counters, kCtrCount));
   HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
@@ -598,6 +604,8 @@ int32_t choose_head(apss_handle *h, bool *changed) {
 
 int32_t build_index(apss_handle *h, int64_t row0) {
   h->st.build_ms = 0;
+  row0 = std::min(row0, h->idx_rows);  // rows waiting in the tail are folded in with this batch
+  h->idx_rows = h->n_rows;
   if (head_allowed(h)) {
     if (h->n_rows >= std::max<int64_t>(h->cfg.head_terms > 0 ? 1 : kHeadMinRows, 2 * h->head_eval_rows)) {
       bool changed = false;
@@ -620,7 +628,7 @@ int32_t build_index(apss_handle *h, int64_t row0) {
     h->ex_built_rows = 0;
   }
   if (h->use_coarse) {
-    if (h->cx.n_tiles == 0 && h->cfg.tile_rows == 0 && !h->dbgcfg.cx_tile && h->n_rows > 0) {
+    if (h->cx.n_tiles == 0 && h->cfg.tile_rows == 0 && !h->dbgcfg.cx_tile && h->idx_rows > 0) {
       // a round's cost is mostly fixed, so what matters is how many postings a (tile, term) segment holds:
       // rows_per_tile * nnz_per_row / dim.  Below ~16 at 32768 rows (C5 shape: 6.5) the 65536-row tile with one
       // 1024-thread workgroup per CU wins (C5 shape at N=2M: 647 vs 790 ms); at C3 (33) two workgroups per CU win.
@@ -634,7 +642,7 @@ int32_t build_index(apss_handle *h, int64_t row0) {
     h->ex_built_rows = std::min(h->ex_built_rows, row0);
     APSS_TRY(ensure_exact_index(h));
   }
-  h->n_tiles = ceil_div(h->n_rows, h->ex.cb);
+  h->n_tiles = ceil_div(h->idx_rows, h->ex.cb);
   return APSS_OK;
 }
 
@@ -770,8 +778,11 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
 // ---- probe the whole index with a query batch resident on the device ----
 // q_head: rows of the batch in the dense-head block (null when the handle has none): the store's W for a stored batch,
 // the staged q_W otherwise.
+int32_t pack_query_head(apss_handle *h, const int64_t *rowptr, const int32_t *idx, const float *val, int64_t nq);
+
+// q_slot_first: slot of query row 0 when the batch is rows of the store (self-join, insert-and-query), else -1.
 int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t *q_idx, const float *q_val,
-              const int64_t *q_ext, const float *q_sub, int64_t q_slot_base, int64_t q_max_nnz, float q_max_norm2,
+              const int64_t *q_ext, int64_t q_slot_first, int64_t q_max_nnz, float q_max_norm2,
               int64_t q_nnz_end, int64_t *n_results) {
   const DebugCfg &dbg = h->dbgcfg;
   h->res_q_ext = q_ext;
@@ -831,20 +842,33 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
                            (q_max_nnz <= 512 || !shard_rule) &&
                            !dbg.exact_accum && cx_scale > 0 && cx_theta < 65000.0 && (shard_rule || cx_theta - 2 >= 1.0) &&
                            std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
+  // rows waiting in the tail are scored pair by pair after the join over the index; that needs the two-pass path's final
+  // list and a bounded number of pairs -- otherwise they are folded into the index first
+  const int64_t tail_n = h->n_rows - h->idx_rows;
+  if (tail_n > 0 && (!(coarse_path && !h->sharded) || nq * tail_n > kTailMaxPairs)) {
+    APSS_TRY(build_index(h, h->idx_rows));
+    return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_slot_first, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
+  }
+  // a stored batch that still waits in the tail is not in the index: for the join over the index it is an outside batch
+  const int64_t q_slot_base = q_slot_first >= 0 && q_slot_first < h->idx_rows ? q_slot_first : -1;
   if (hybrid_wanted && !(coarse_path && mode == 0 && head_thr >= 0.5 * theta)) {
     // this call cannot take the hybrid path (signed or very long queries, norms out of range ...): the dense block's
     // terms go back into the inverted index, for good, and the call runs as on a handle without a block
     h->head_blocked = true;
     APSS_TRY(build_index(h, 0));
-    return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_sub, q_slot_base, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
+    return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_slot_first, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
   }
   const bool hybrid = hybrid_wanted;
+  // the batch's rows of the dense-head block and its tail ratios: the store's were packed when it was indexed; an outside
+  // batch (or one waiting in the tail) is packed here
+  if (hybrid && q_slot_base < 0) APSS_TRY(pack_query_head(h, q_rowptr, q_idx, q_val, nq));
+  const float *q_sub = !shard_rule ? nullptr : (q_slot_base >= 0 ? h->sub.p + q_slot_base : h->q_sub.p);
 
   ProbeArgs a{};
   a.seg_stride = (int64_t)h->cfg.dim;
   a.ext_id = h->ext.p;
   a.c_scale = shard_rule ? h->sub.p : nullptr;
-  a.n_rows = h->n_rows;
+  a.n_rows = h->idx_rows;
   a.q_rowptr = q_rowptr;
   a.q_idx = q_idx;
   a.q_val = q_val;
@@ -1029,7 +1053,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
       HIPCHK(h, hipEventRecord(h->ev2, h->stream));
       const bool stored = q_slot_base >= 0;
-      APSS_TRY(run_head(h, a, nq, q_slot_base, stored ? h->W.p : h->q_W.p, stored ? (int64_t)(h->W.cap / h->head_k) : ceil_div(nq, kHeadCTile) * kHeadCTile, head_thr, h->n_rows));
+      APSS_TRY(run_head(h, a, nq, q_slot_base, stored ? h->W.p : h->q_W.p, stored ? (int64_t)(h->W.cap / h->head_k) : ceil_div(nq, kHeadCTile) * kHeadCTile, head_thr, h->idx_rows));
       HIPCHK(h, hipEventRecord(h->ev3, h->stream));
       HIPCHK(h, hipMemcpyAsync(head_c, h->head_ctr.p, sizeof(head_c), hipMemcpyDeviceToHost, h->stream));
     }
@@ -1127,6 +1151,40 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
         h->st.rescore_ms = ms;
         h->n_res = (int64_t)nfin;
       }
+      if (tail_n > 0) {
+        // the rows that wait outside the index: every (query, tail row) pair, exactly (k_tail_score)
+        const int64_t pairs = nq * tail_n;
+        APSS_TRY(ensure(h, h->fin_q, (size_t)(h->n_res + pairs), (size_t)h->n_res));
+        APSS_TRY(ensure(h, h->fin_c, (size_t)(h->n_res + pairs), (size_t)h->n_res));
+        APSS_TRY(ensure(h, h->fin_s, (size_t)(h->n_res + pairs), (size_t)h->n_res));
+        HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
+        TailArgs t{};
+        t.nq = nq;
+        t.n_tail = tail_n;
+        t.q_rowptr = q_rowptr;
+        t.q_idx = q_idx;
+        t.q_val = q_val;
+        t.q_ext = q_ext;
+        t.c_rowptr = h->rowptr.p;
+        t.c_idx = h->idx.p;
+        t.c_val = h->val.p;
+        t.c_ext = h->ext.p;
+        t.tail0 = h->idx_rows;
+        t.theta = (float)theta;
+        t.out_q = h->fin_q.p;
+        t.out_c = h->fin_c.p;
+        t.out_s = h->fin_s.p;
+        t.out_base = h->n_res;
+        t.counters = h->counters.p;
+        hipLaunchKernelGGL(k_tail_score, dim3((unsigned)ceil_div(pairs * kGroup, 256)), dim3(256), 0, h->stream, t);
+        HIPCHK(h, hipGetLastError());
+        unsigned long long tc[kCtrCount];
+        HIPCHK(h, hipMemcpyAsync(tc, h->counters.p, sizeof(tc), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->n_res += (int64_t)tc[kCtrResults];
+        h->st.posting_visits += (int64_t)tc[kCtrVisits];
+        h->st.candidate_pairs += (int64_t)tc[kCtrCands];
+      }
       h->out_q = h->fin_q.p;
       h->out_c = h->fin_c.p;
       h->out_s = h->fin_s.p;
@@ -1196,7 +1254,38 @@ int32_t insert_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d
   const int64_t row0 = h->n_rows;
   h->n_rows += kept_rows;
   h->nnz += kept_nnz;
+  // a small batch onto an existing index waits in the TAIL (k_tail_score scores it directly) until the tail is worth a
+  // rebuild of the last tile: a single-vector message then costs no pass over the dim-wide segment table
+  const bool tail_ok = h->use_coarse && !h->sharded && h->idx_rows > 0 && !h->dbgcfg.no_tail;
+  if (tail_ok && kept_rows <= kTailMaxBatch && h->n_rows - h->idx_rows <= kTailMaxRows) {
+    h->st.build_ms = 0;
+    return APSS_OK;
+  }
   APSS_TRY(build_index(h, row0));
+  return APSS_OK;
+}
+
+// rows of the dense-head block and tail ratios of a query batch given as CSR with absolute row offsets
+int32_t pack_query_head(apss_handle *h, const int64_t *rowptr, const int32_t *idx, const float *val, int64_t nq) {
+  const int64_t q_pad = ceil_div(nq, kHeadCTile) * kHeadCTile;
+  APSS_TRY(ensure(h, h->q_W, (size_t)(q_pad * h->head_k)));
+  APSS_TRY(ensure(h, h->q_sub, (size_t)nq));
+  HeadPackArgs a{};
+  a.rowptr = rowptr;
+  a.idx = idx;
+  a.val = val;
+  a.row0 = 0;
+  a.row1 = nq;
+  a.head_pos = h->head_pos.p;
+  a.kh = h->head_k;
+  a.W = h->q_W.p;
+  a.w_row0 = 0;
+  a.w_pad = q_pad;
+  a.ratio_t = h->q_sub.p;
+  a.idx_tail = nullptr;
+  a.head_nonempty = nullptr;
+  hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(q_pad, 8)), dim3(512), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
   return APSS_OK;
 }
 
@@ -1204,30 +1293,10 @@ int32_t query_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_
                        const float *d_val, const int64_t *d_ext, int64_t *n_results) {
   int64_t kept_rows = 0, kept_nnz = 0;
   APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, false, &kept_rows, &kept_nnz));
-  if (h->head_k && kept_rows > 0) {
-    // the batch's rows of the dense-head block and its tail ratios (the store's were packed when it was indexed)
-    const int64_t q_pad = ceil_div(kept_rows, kHeadCTile) * kHeadCTile;
-    APSS_TRY(ensure(h, h->q_W, (size_t)(q_pad * h->head_k)));
-    APSS_TRY(ensure(h, h->q_sub, (size_t)kept_rows));
-    HeadPackArgs a{};
-    a.rowptr = h->q_rowptr.p;
-    a.idx = h->q_idx.p;
-    a.val = h->q_val.p;
-    a.row0 = 0;
-    a.row1 = kept_rows;
-    a.head_pos = h->head_pos.p;
-    a.kh = h->head_k;
-    a.W = h->q_W.p;
-    a.w_row0 = 0;
-    a.w_pad = q_pad;
-    a.ratio_t = h->q_sub.p;
-    a.idx_tail = nullptr;
-    a.head_nonempty = nullptr;
-    hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(q_pad, 8)), dim3(512), 0, h->stream, a);
-    HIPCHK(h, hipGetLastError());
-  }
-  return probe(h, kept_rows, h->q_rowptr.p, h->q_idx.p, h->q_val.p, h->q_ext.p, h->q_sub.p, -1, h->q_max_nnz, h->q_max_norm2,
-               kept_nnz, n_results);
+  // the batch's rows of the dense-head block and its tail ratios (the store's were packed when it was indexed)
+  if (h->head_k && kept_rows > 0) APSS_TRY(pack_query_head(h, h->q_rowptr.p, h->q_idx.p, h->q_val.p, kept_rows));
+  return probe(h, kept_rows, h->q_rowptr.p, h->q_idx.p, h->q_val.p, h->q_ext.p, -1, h->q_max_nnz, h->q_max_norm2, kept_nnz,
+               n_results);
 }
 
 }  // namespace
@@ -1380,8 +1449,8 @@ int32_t apss_insert_and_query(apss_handle *h, int64_t n, const int64_t *rowptr, 
 
 int32_t apss_self_join(apss_handle *h, int64_t *n_results) {
   APSS_TRY(enter(h));
-  return probe(h, h->n_rows, h->rowptr.p, h->idx.p, h->val.p, h->ext.p, h->sub.p, 0, h->store_max_nnz, h->store_max_norm2, h->nnz,
-               n_results);
+  if (h->idx_rows < h->n_rows) APSS_TRY(build_index(h, h->idx_rows));  // a self-join runs over the index: fold the tail in
+  return probe(h, h->n_rows, h->rowptr.p, h->idx.p, h->val.p, h->ext.p, 0, h->store_max_nnz, h->store_max_norm2, h->nnz, n_results);
 }
 
 int32_t apss_result_count(const apss_handle *h, int64_t *n_results) {
@@ -1432,7 +1501,7 @@ int32_t apss_stats_get(apss_handle *h, apss_stats *out) {
   if (!h || !out) return APSS_E_INVALID;
   h->st.rows = h->n_rows;
   h->st.nnz = h->nnz;
-  h->st.tiles = h->use_coarse && h->ex_built_rows < h->n_rows ? h->cx.n_tiles : ceil_div(h->n_rows, h->ex.cb);
+  h->st.tiles = h->use_coarse && h->ex_built_rows < h->idx_rows ? h->cx.n_tiles : ceil_div(h->idx_rows, h->ex.cb);
   h->st.hbm_bytes = (int64_t)h->bytes_reserved;
   *out = h->st;
   return APSS_OK;
@@ -1468,14 +1537,15 @@ int32_t apss_insert_and_query_dev(apss_handle *h, int64_t n, int64_t nnz, const 
   APSS_TRY(insert_dev_impl(h, n, nnz, d_rowptr, d_indices, d_values, d_ext_ids, &first));
   const int64_t nq = h->n_rows - first;
   // the batch is now rows [first, n_rows) of the store: query it in place (rowptr offsets are absolute)
-  return probe(h, nq, h->rowptr.p + first, h->idx.p, h->val.p, h->ext.p + first, (h->sharded || h->head_k) ? h->sub.p + first : nullptr,
-               first, h->store_max_nnz, h->store_max_norm2, h->nnz, n_results);
+  return probe(h, nq, h->rowptr.p + first, h->idx.p, h->val.p, h->ext.p + first, first, h->store_max_nnz, h->store_max_norm2, h->nnz,
+               n_results);
 }
 
 int32_t apss_clear(apss_handle *h) {
   APSS_TRY(enter(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->n_rows = 0;
+  h->idx_rows = 0;
   h->nnz = 0;
   h->n_tiles = 0;
   for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { s->n_tiles = 0; s->post_used = 0; s->h_base.clear(); }

@@ -1736,6 +1736,80 @@ __global__ void k_rescore(RescoreArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_tail_score: the rows a stream of small batches appended since the index was last extended (the TAIL: at most a few
+// thousand) are not in the tile index yet -- folding every single-vector message into it costs a pass over a dim-wide
+// segment table (2 ms at vectorDim 2^20, the reference's production shape).  A query batch scores them directly: every
+// (query, tail row) pair, 16 lanes per pair, exact fp32 dot over the two sorted rows (CU:98-117), `>= theta` (IWA:93),
+// self-exclusion by external id (IWA:91); a pair counts as a candidate iff it shares a term (IWA:86: it is reached through
+// a posting list), and its shared terms count as posting visits.  Appends to the final result list.
+struct TailArgs {
+  int64_t nq, n_tail;
+  const int64_t *q_rowptr;  // absolute offsets into q_idx / q_val
+  const int32_t *q_idx;
+  const float *q_val;
+  const int64_t *q_ext;
+  const int64_t *c_rowptr;  // the store's rowptr; tail rows are slots tail0 .. tail0 + n_tail
+  const int32_t *c_idx;
+  const float *c_val;
+  const int64_t *c_ext;
+  int64_t tail0;
+  float theta;
+  int32_t *out_q, *out_c;
+  float *out_s;
+  int64_t out_base;               // results already in the list
+  unsigned long long *counters;   // [kCtrResults] appended here, [kCtrVisits] shared terms, [kCtrCands] pairs sharing a term
+};
+
+__global__ void k_tail_score(TailArgs a) {
+  const int64_t pair = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  const bool live = pair < a.nq * a.n_tail;
+  float s = 0.f;
+  int matches = 0;
+  int64_t qr = 0, cs = 0;
+  if (live) {
+    qr = pair / a.n_tail;
+    cs = a.tail0 + pair % a.n_tail;
+    const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
+    const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
+    for (int64_t k = qb + gl; k < qe; k += kGroup) {
+      const int32_t t = a.q_idx[k];
+      int64_t lo = cb, hi = ce;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+      }
+      if (lo < ce && a.c_idx[lo] == t) {
+        s += a.q_val[k] * a.c_val[lo];
+        matches++;
+      }
+    }
+  }
+  for (int o = kGroup / 2; o; o >>= 1) {
+    s += __shfl_xor(s, o, kGroup);
+    matches += __shfl_xor(matches, o, kGroup);
+  }
+  const bool shares = live && gl == 0 && matches > 0;  // reached through a posting list (its own row included, as in the index)
+  const bool lead = shares && a.q_ext[qr] != a.c_ext[cs];
+  const bool keep = lead && s >= a.theta;
+  if (__ballot(shares)) {
+    int v = shares ? matches : 0;
+    for (int o = kWave / 2; o; o >>= 1) v += __shfl_xor(v, o);
+    const unsigned long long touched = __ballot(lead);
+    if (__lane_id() == 0) {
+      atomicAdd(&a.counters[kCtrVisits], (unsigned long long)v);
+      if (touched) atomicAdd(&a.counters[kCtrCands], (unsigned long long)__popcll(touched));
+    }
+  }
+  const uint64_t o = wave_append(keep, &a.counters[kCtrResults]);
+  if (keep) {
+    a.out_q[a.out_base + o] = (int32_t)qr;
+    a.out_c[a.out_base + o] = (int32_t)cs;
+    a.out_s[a.out_base + o] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // exact partial score of named pairs over the shard's dims (two sorted index lists, 16 lanes per pair:
 // each lane binary-searches its share of the query's entries in the candidate row)
 struct PartialArgs {

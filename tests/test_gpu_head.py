@@ -61,18 +61,36 @@ def test_head_pairs_count_is_exact(engine):
     assert st["head_pairs"] == truth
 
 
-def test_c2_size_zipf1_auto_policy(engine, oracle):
-    """BASELINE.json configs[1] at full size (N=100k, dim=10k, nnz=50, Zipf(1), theta=0.5): the library decides on the
-    block by itself; result set against the oracle on a query sample (the oracle needs seconds per thousand queries),
-    and against the plain path on the whole batch"""
+def test_c2_size_zipf1_policy_and_forced_block(engine, oracle):
+    """BASELINE.json configs[1] at full size (N=100k, dim=10k, nnz=50, Zipf(1), theta=0.5).  Left to itself the library
+    samples the dense filter's selectivity and declines the block here (at theta = 0.5 it would pass a quarter of a
+    percent of all pairs on to re-scoring: more work than the posting visits it saves); with the block forced the
+    result set is the same.  Both against the oracle on a query sample (the oracle needs seconds per thousand queries)"""
     cfg, rp, idx, val = synth.make_config("c2")
     n, dim, theta = cfg["n"], cfg["dim"], cfg["theta"]
-    got, st = _join(engine, dim, theta, rp, idx, val)
-    assert st["head_terms"] in (64, 128, 256), st
-    ref, st0 = _join(engine, dim, theta, rp, idx, val, head_terms=-1)
+    ref, st0 = _join(engine, dim, theta, rp, idx, val)
+    assert st0["head_terms"] == 0, st0
+    got, st = _join(engine, dim, theta, rp, idx, val, head_terms=256)
+    assert st["head_terms"] == 256 and st["head_survivors"] > 100 * len(got)
     assert ref.keys() == got.keys() and len(got) > 1000
     assert max(abs(got[k] - ref[k]) for k in got) <= 2e-6
     sample = 1500
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val, 0, sample))
+    assert len(want) > 10
+    assert_same_pairs({k: v for k, v in got.items() if k[0] < sample}, want, theta)
+
+
+def test_c3_shape_zipf1_auto_policy(engine, oracle):
+    """C3's shape with Zipf(1) terms at N = 60k (theta = 0.8): here the library takes the block by itself; result set
+    against the plain path on the whole batch and against the oracle on a query sample"""
+    cfg, rp, idx, val = synth.make_config("c3z1", n=60_000, device="cuda")
+    dim, theta = cfg["dim"], cfg["theta"]
+    got, st = _join(engine, dim, theta, rp, idx, val)
+    assert st["head_terms"] in (64, 128, 256) and st["head_pairs"] > 0, st
+    ref, st0 = _join(engine, dim, theta, rp, idx, val, head_terms=-1)
+    assert st0["head_terms"] == 0 and ref.keys() == got.keys() and len(got) > 1000
+    assert st["posting_visits"] < st0["posting_visits"] // 10
+    sample = 1000
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val, 0, sample))
     assert len(want) > 10
     assert_same_pairs({k: v for k, v in got.items() if k[0] < sample}, want, theta)

@@ -3,6 +3,7 @@ and thresholds, all three probe paths, against the CPU oracle's IndexingWorkerAc
 import numpy as np
 import pytest
 
+from apss import synth
 from helpers import assert_same_pairs, to_map
 
 pytestmark = pytest.mark.gpu
@@ -58,3 +59,40 @@ def test_random_streams(oracle, seed, monkeypatch):
             assert_same_pairs(got, want, theta)
         # the reference's output map is keyed by id: duplicates collapse to one entry per (q id, c id)
         assert ix.size()[0] == len(ids)
+
+
+@pytest.mark.parametrize("head", [-1, 64])
+def test_single_vector_messages_wait_in_the_tail(oracle, head):
+    """the LoadGenerator shape (benchmark/LoadGenerator.scala:58-74): after a warm-up batch, thousands of single-vector
+    IndexData messages.  They wait in the tail (scored pair by pair, k_tail_score) and are folded into the tile index
+    every 4096 rows; every message's answer equals the oracle worker's, including pairs between two tail rows, and a
+    final self-join (tail folded in) equals the oracle's"""
+    from apss.engine import ApssIndex
+    n0, n1, dim, nnz, theta = 2000, 4400, 900, 14, 0.55
+    rp, idx, val = synth.make_vectors(n0 + n1, dim, nnz, 1.0 if head > 0 else 0.0, seed=321, dup_frac=0.3)
+    w = oracle.Worker(dim, theta)
+    with ApssIndex(dim, theta, tile_rows=512, head_terms=head) as ix:
+        e0 = int(rp[n0])
+        want = to_map(*w.index_data(np.arange(n0), rp[:n0 + 1], idx[:e0], val[:e0]))
+        assert_same_pairs(to_map(*ix.insert_and_query(np.arange(n0), rp[:n0 + 1], idx[:e0], val[:e0])), want, theta)
+        found = 0
+        r = n0
+        sizes = [1] * 4200 + [3, 7, 1, 60, 1, 1, 120, 1, 5]
+        for sz in sizes:
+            sl = slice(rp[r], rp[r + sz])
+            args = (np.arange(r, r + sz), rp[r:r + sz + 1] - rp[r], idx[sl], val[sl])
+            want = to_map(*w.index_data(*args))
+            got = to_map(*ix.insert_and_query(*args))
+            assert_same_pairs(got, want, theta)
+            found += len(got)
+            r += sz
+        assert found > 1000 and ix.size()[0] == r
+        st = ix.stats()
+        assert st["head_terms"] == (64 if head > 0 else 0)
+        # frozen-index query while rows wait in the tail
+        sl = slice(rp[100], rp[140])
+        got = to_map(*ix.query(np.arange(100, 140), rp[100:141] - rp[100], idx[sl], val[sl]))
+        want = to_map(*w.index_data(np.arange(100, 140), rp[100:141] - rp[100], idx[sl], val[sl], query_only=True))
+        assert_same_pairs(got, want, theta)
+        full = to_map(*oracle.selfjoin_pairs(dim, theta, rp[:r + 1], idx[:rp[r]], val[:rp[r]]))
+        assert_same_pairs(to_map(*ix.self_join()), full, theta)
