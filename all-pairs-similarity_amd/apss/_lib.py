@@ -50,6 +50,29 @@ def build(force=False):
 _lib = None
 
 
+def hip_runtimes_loaded():
+    """paths of the libamdhip64 images mapped into this process (there must never be two)"""
+    with open("/proc/self/maps") as f:
+        return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+
+
+def _one_hip_runtime():
+    """ONE HIP runtime per process, whatever the import order.  PyTorch-ROCm bundles its own libamdhip64 (soname
+    libamdhip64.so.7, found through libtorch_hip's RPATH); libapss_hip.so asks for the same soname.  The dynamic loader
+    reuses an image whose soname matches, so: if torch is installed, its bundled runtime is mapped FIRST (by path, without
+    importing torch) -- libapss_hip.so then binds to it, and a later `import torch` finds its own file already mapped.
+    Without torch (the C++ host mirror, the JVM) the system runtime of /opt/rocm is the only one there is."""
+    import importlib.util
+    if hip_runtimes_loaded():
+        return  # torch (or another HIP user) came first: libapss_hip.so binds to that image by soname
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Loads libapss_hip.so; raises if it has not been built (there is no CPU path to fall back to)."""
     global _lib
@@ -58,12 +81,7 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise RuntimeError("libapss_hip.so is not built (%s): run __graft_entry__.build() / make -C %s. "
                            "There is no CPU fallback." % (SO_PATH, CSRC))
-    # PyTorch-ROCm ships its own HIP runtime; if it is going to be used in this process (device-pointer entry points,
-    # apss.dist) it has to be loaded before ours pulls in the system's libamdhip64, or the second runtime finds no device
-    import importlib.util
-    import sys
-    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
-        import torch  # noqa: F401
+    _one_hip_runtime()
     L = C.CDLL(SO_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
     pi64 = C.POINTER(C.c_int64)

@@ -88,7 +88,7 @@ __global__ void k_ingest_count(IngestArgs a) {
     e = a.rowptr[row + 1];
   }
   unsigned bad = 0;
-  if (b < 0 || e < b || e > a.nnz) {  // malformed extents: flag the batch and read nothing
+  if (b < 0 || e < b || e > a.nnz || (row == 0 && b != 0)) {  // malformed extents (a batch's rowptr starts at 0): flag the batch and read nothing
     bad |= 1;
     b = e = 0;
   }

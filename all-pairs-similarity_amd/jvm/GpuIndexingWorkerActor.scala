@@ -13,7 +13,7 @@ import cpslab.message._
   * messages in (IndexData, IOTicket, ReceiveTimeout, Test), same SimilarityOutput out, same config keys; the
   * vectorsStore / invertedIndex / calculateSimilarity loop is replaced by one JNI call per batch.
   * EntryProxyActor.handleDataPacket keeps sending it IndexData; with the GPU index a single worker per entry is enough
-  * (maxIndexEntryActorNum = 1), since every worker of the reference recomputes the same full score anyway.
+  * (maxIndexEntryActorNum = 1, maxShardNum = 1), since every worker of the reference recomputes the same full score anyway.
   * Source only: not compiled in the build image (no JVM there). */
 private class GpuIndexingWorkerActor(conf: Config) extends Actor {
   val similarityThreshold = conf.getDouble("cpslab.allpair.similarityThreshold")
@@ -21,7 +21,15 @@ private class GpuIndexingWorkerActor(conf: Config) extends Actor {
   val outputWritingDuration = conf.getLong("cpslab.allpair.outputIODuration")
   val writeBuffer = new mutable.HashMap[String, mutable.HashMap[String, Double]]
   private val expDuration = conf.getLong("cpslab.allpair.benchmark.expDuration")
-  private val handle = NativeApss.create(vectorDim, similarityThreshold, 0.0, 0, 0)
+  // WriteWorkerActor.scala:35,188-194 drops entries <= indexThreshold before a vector reaches this actor; the key is read here
+  // too so that a deployment that feeds the actor directly gets the same pruning on the device
+  private val indexThreshold =
+    if (conf.hasPath("cpslab.allpair.indexThreshold")) conf.getDouble("cpslab.allpair.indexThreshold") else 0.0
+  // which GPU this worker's index lives on (one handle = one GPU's HBM); GPU keys of this build: cpslab.allpair.gpu.*
+  private val device = if (conf.hasPath("cpslab.allpair.gpu.device")) conf.getInt("cpslab.allpair.gpu.device") else 0
+  private val headTerms = if (conf.hasPath("cpslab.allpair.gpu.headTerms")) conf.getInt("cpslab.allpair.gpu.headTerms") else 0
+  private val handle = NativeApss.create(vectorDim, similarityThreshold, indexThreshold,
+    if (indexThreshold > 0.0) NativeApss.FLAG_VALUE_PRUNE else 0, device, headTerms)
   require(handle != 0L, NativeApss.lastError(0L))
   private val idOf = new mutable.HashMap[String, Long]
   private val nameOf = new mutable.ArrayBuffer[String]
@@ -43,6 +51,12 @@ private class GpuIndexingWorkerActor(conf: Config) extends Actor {
 
   private def runBatch(vectors: Set[cpslab.vector.SparseVectorWrapper]):
       mutable.HashMap[String, mutable.HashMap[String, Double]] = {
+    // The whole vector is indexed and scored here, so it must arrive ONCE: with maxShardNum > 1 the reference sends the
+    // same full vector in one DataPacket per shard, each naming that shard's dims in wrapper.indices
+    // (WriteWorkerActor.scala:166-179), and it would be stored and queried once per packet.  Deploy with
+    // cpslab.allpair.maxShardNum = 1 (and maxIndexEntryActorNum = 1): INTEGRATION.md.
+    vectors.foreach(w => require(w.indices.size == w.sparseVector._2.indices.length,
+      "GpuIndexingWorkerActor needs the whole vector in one DataPacket: set cpslab.allpair.maxShardNum = 1"))
     val batch = vectors.toArray.map(_.sparseVector)           // (String id, SparseVector)
     val rowptr = new Array[Long](batch.length + 1)
     val ids = new Array[Long](batch.length)

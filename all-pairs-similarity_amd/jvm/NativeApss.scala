@@ -5,7 +5,10 @@ package cpslab.gpu
 object NativeApss {
   System.loadLibrary("apss_jni")
   val FLAG_VALUE_PRUNE = 1
-  @native def create(dim: Int, theta: Double, indexThreshold: Double, flags: Int, device: Int): Long
+  val FLAG_ADMISSION = 2
+  val FLAG_NORMALIZE = 4
+  /** headTerms: dense-head block of the library (0 = it decides from the term distribution, -1 = never) */
+  @native def create(dim: Int, theta: Double, indexThreshold: Double, flags: Int, device: Int, headTerms: Int): Long
   @native def destroy(h: Long): Unit
   @native def lastError(h: Long): String
   /** mode 0 insert, 1 query on the frozen index, 2 insert-and-query; returns #results or a negative status */

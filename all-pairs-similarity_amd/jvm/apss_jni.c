@@ -1,22 +1,29 @@
 /*
  * apss_jni.c -- JNI shim: forwards cpslab.gpu.NativeApss 1:1 to the C ABI of include/apss.h.
  *
- * NOT compiled in this repository's image (no JDK / jni.h here); a maintainer builds it next to the reference with
+ * NOT compiled in this repository's image (no JDK / jni.h here; tests/test_jni_shim_syntax.py type-checks it against a
+ * minimal declaration of the JNI functions it uses); a maintainer builds it next to the reference with
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
  *       all-pairs-similarity_amd/jvm/apss_jni.c -Lall-pairs-similarity_amd/csrc -lapss_hip -o libapss_jni.so
- * The shim holds no state and does no arithmetic: array pinning, the call, the status code.
+ * The shim holds no state and does no arithmetic: copy the arrays out of the Java heap, the call, the status code.
+ *
+ * No GetPrimitiveArrayCritical: the library calls block on H2D copies, kernels and stream syncs, and JNI forbids blocking
+ * inside a critical region (the collector would stall for the whole join).  Batches are copied with Get<T>ArrayRegion
+ * into C buffers first (a batch is a few MB; the PCIe copy that follows costs more), results go back with
+ * Set<T>ArrayRegion.  Array lengths are checked against the CSR they describe before anything is dereferenced.
  */
 #if defined(__has_include)
 #if __has_include(<jni.h>)
 #include <jni.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "apss.h"
 
 #define H(x) ((apss_handle *)(intptr_t)(x))
 
 JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_create(JNIEnv *env, jclass cls, jint dim, jdouble theta,
-                                                          jdouble indexThreshold, jint flags, jint device) {
+                                                          jdouble indexThreshold, jint flags, jint device, jint headTerms) {
   (void)env; (void)cls;
   apss_config c = {0};
   c.struct_size = (int32_t)sizeof(c);
@@ -25,6 +32,7 @@ JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_create(JNIEnv *env, jclass cl
   c.index_threshold = indexThreshold;
   c.flags = (uint32_t)flags;
   c.device_id = device;
+  c.head_terms = headTerms;
   apss_handle *h = 0;
   return apss_create(&c, &h) == APSS_OK ? (jlong)(intptr_t)h : 0;
 }
@@ -44,32 +52,62 @@ JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_submit(JNIEnv *env, jclass cl
                                                           jintArray indices, jdoubleArray values, jlongArray ids) {
   (void)cls;
   const jsize n = (*env)->GetArrayLength(env, ids);
-  jlong *rp = (*env)->GetPrimitiveArrayCritical(env, rowptr, 0);
-  jint *ix = (*env)->GetPrimitiveArrayCritical(env, indices, 0);
-  jdouble *vl = (*env)->GetPrimitiveArrayCritical(env, values, 0);
-  jlong *id = (*env)->GetPrimitiveArrayCritical(env, ids, 0);
-  int64_t n_res = 0;
-  int32_t rc;
-  if (mode == 0) rc = apss_insert(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id);
-  else if (mode == 1) rc = apss_query(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id, &n_res);
-  else rc = apss_insert_and_query(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id, &n_res);
-  (*env)->ReleasePrimitiveArrayCritical(env, ids, id, JNI_ABORT);
-  (*env)->ReleasePrimitiveArrayCritical(env, values, vl, JNI_ABORT);
-  (*env)->ReleasePrimitiveArrayCritical(env, indices, ix, JNI_ABORT);
-  (*env)->ReleasePrimitiveArrayCritical(env, rowptr, rp, JNI_ABORT);
-  return rc == APSS_OK ? (jlong)n_res : (jlong)rc;
+  const jsize n_rp = (*env)->GetArrayLength(env, rowptr);
+  const jsize n_ix = (*env)->GetArrayLength(env, indices);
+  const jsize n_vl = (*env)->GetArrayLength(env, values);
+  if (n_rp != n + 1 || n_ix != n_vl) return (jlong)APSS_E_INVALID; /* the CSR does not describe n rows */
+  jlong *rp = (jlong *)malloc(sizeof(jlong) * (size_t)(n + 1));
+  jlong *id = (jlong *)malloc(sizeof(jlong) * (size_t)(n > 0 ? n : 1));
+  jint *ix = (jint *)malloc(sizeof(jint) * (size_t)(n_ix > 0 ? n_ix : 1));
+  jdouble *vl = (jdouble *)malloc(sizeof(jdouble) * (size_t)(n_vl > 0 ? n_vl : 1));
+  jlong out = (jlong)APSS_E_NOMEM;
+  if (rp && id && ix && vl) {
+    (*env)->GetLongArrayRegion(env, rowptr, 0, n + 1, rp);
+    (*env)->GetLongArrayRegion(env, ids, 0, n, id);
+    (*env)->GetIntArrayRegion(env, indices, 0, n_ix, ix);
+    (*env)->GetDoubleArrayRegion(env, values, 0, n_vl, vl);
+    if ((*env)->ExceptionCheck(env)) {
+      out = (jlong)APSS_E_INVALID;
+    } else if (rp[0] != 0 || rp[n] != (jlong)n_ix) { /* the library checks monotonicity and the indices themselves */
+      out = (jlong)APSS_E_INVALID;
+    } else {
+      int64_t n_res = 0;
+      int32_t rc;
+      if (mode == 0) rc = apss_insert(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id);
+      else if (mode == 1) rc = apss_query(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id, &n_res);
+      else rc = apss_insert_and_query(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id, &n_res);
+      out = rc == APSS_OK ? (jlong)n_res : (jlong)rc;
+    }
+  }
+  free(vl);
+  free(ix);
+  free(id);
+  free(rp);
+  return out;
 }
 
 JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_fetch(JNIEnv *env, jclass cls, jlong h, jlong count, jlongArray outQ,
                                                         jlongArray outC, jfloatArray outScore) {
   (void)cls;
-  jlong *q = (*env)->GetPrimitiveArrayCritical(env, outQ, 0);
-  jlong *c = (*env)->GetPrimitiveArrayCritical(env, outC, 0);
-  jfloat *s = (*env)->GetPrimitiveArrayCritical(env, outScore, 0);
-  const int32_t rc = apss_fetch_results(H(h), 0, count, (int64_t *)q, (int64_t *)c, s);
-  (*env)->ReleasePrimitiveArrayCritical(env, outScore, s, 0);
-  (*env)->ReleasePrimitiveArrayCritical(env, outC, c, 0);
-  (*env)->ReleasePrimitiveArrayCritical(env, outQ, q, 0);
+  if (count < 0 || (*env)->GetArrayLength(env, outQ) < count || (*env)->GetArrayLength(env, outC) < count ||
+      (*env)->GetArrayLength(env, outScore) < count)
+    return APSS_E_INVALID;
+  if (count == 0) return APSS_OK;
+  int64_t *q = (int64_t *)malloc(sizeof(int64_t) * (size_t)count);
+  int64_t *c = (int64_t *)malloc(sizeof(int64_t) * (size_t)count);
+  float *s = (float *)malloc(sizeof(float) * (size_t)count);
+  int32_t rc = APSS_E_NOMEM;
+  if (q && c && s) {
+    rc = apss_fetch_results(H(h), 0, count, q, c, s);
+    if (rc == APSS_OK) {
+      (*env)->SetLongArrayRegion(env, outQ, 0, (jsize)count, (const jlong *)q);
+      (*env)->SetLongArrayRegion(env, outC, 0, (jsize)count, (const jlong *)c);
+      (*env)->SetFloatArrayRegion(env, outScore, 0, (jsize)count, s);
+    }
+  }
+  free(s);
+  free(c);
+  free(q);
   return rc;
 }
 #endif

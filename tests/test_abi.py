@@ -49,3 +49,15 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".scala", ".c")):
                 txt = open(os.path.join(d, f)).read()
                 assert not pat.search(txt), (d, f)
+
+
+def test_one_hip_runtime_whatever_the_import_order(so):
+    """libapss_hip.so loaded BEFORE torch and torch imported afterwards: still one libamdhip64 image in the process
+    (it used to depend on importing torch first)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from apss import _lib; _lib.lib(); a = _lib.hip_runtimes_loaded(); "
+            "import torch; b = _lib.hip_runtimes_loaded(); print(len(a), len(b), a == b)") % os.path.join(ROOT, "all-pairs-similarity_amd")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    assert out.stdout.split() == ["1", "1", "True"], out.stdout

@@ -213,6 +213,12 @@ def test_error_codes(apss_mod):
             ix.insert([1], [0, 1], [2], [float("nan")])
         assert e.value.code == _lib.E_INVALID
         assert ix.size() == (0, 0)  # failed batches leave no trace
+        # device-pointer entry points validate on the device: a batch whose rowptr does not start at 0 is malformed
+        import torch
+        dv = lambda a, t: torch.tensor(a, dtype=t, device="cuda")  # noqa: E731
+        with pytest.raises(apss_mod.ApssError) as e:
+            ix.insert_dev(dv([1], torch.int64), dv([1, 2], torch.int64), dv([2, 3], torch.int32), dv([1.0, 1.0], torch.float32))
+        assert e.value.code == _lib.E_INVALID and ix.size() == (0, 0)
         ix.insert([1], [0, 1], [2], [1.0])
         assert ix.size() == (1, 1)
     with pytest.raises(apss_mod.ApssError):
