@@ -115,8 +115,8 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
       if (hp >= 0) rowbuf[wv][hp] = f32_to_bf16_rn(a.val[k] * scale);
     }
     if (lane == 0) {
-      // rounded UP a hair: the scale only ever lowers the sparse filter's threshold
-      a.ratio_t[wr] = full2 > 0.f ? fminf(1.0f, sqrtf(t2 / full2) * 1.000001f) : 0.f;
+      // rounded DOWN a hair: the sparse filter divides the row's tail weights by it (errs on the side of reporting more)
+      a.ratio_t[wr] = full2 > 0.f ? fminf(1.0f, sqrtf(t2 / full2)) * 0.999999f : 0.f;
       if (h2 > 0.f) atomicAdd(&nz, 1u);
     }
   }

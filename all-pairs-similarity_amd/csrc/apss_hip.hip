@@ -374,6 +374,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.coarse = ix.coarse ? 1 : 0;
   b.seg_align = ix.align;
   b.erow = h->erow.p;
+  b.row_scale = scaled && ix.coarse ? h->sub.p : nullptr;  // shard rule: postings normalised by |x_g| / |x| (k_probe_coarse)
   b.coarse_shift = ix.coarse && ix.cb <= 32768 ? 1 : 0;  // must agree with k_probe_coarse's SLOT2 (the 512-thread kernels)
   const int threads = 256;
   const int64_t blocks = ceil_div((h->idx_rows - r0) * kWave, threads);
@@ -657,36 +658,38 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
 
 // ---- the filter kernel's instantiations: (threads, register-window steps, shard rule, postings per chunk, virtual
 // rows, signed weights).  One table, one lookup: a combination that is not listed is an error, never another kernel.
-#define APSS_CX_VARIANTS(X)            \
-  X(512, 5, false, 16, false, false)   \
-  X(512, 4, false, 16, false, false)   \
-  X(512, 3, false, 16, false, false)   \
-  X(512, 2, false, 16, false, false)   \
-  X(512, 5, true, 16, false, false)    \
-  X(512, 4, true, 16, false, false)    \
-  X(512, 3, true, 16, false, false)    \
-  X(512, 2, true, 16, false, false)    \
-  X(512, 4, false, 8, false, false)    \
-  X(512, 5, false, 16, true, false)    \
-  X(512, 5, false, 16, false, true)    \
-  X(512, 5, false, 16, true, true)     \
-  X(1024, 5, false, 16, false, false)  \
-  X(1024, 3, false, 16, false, false)  \
-  X(1024, 5, false, 16, true, false)   \
-  X(1024, 3, false, 16, true, false)   \
-  X(1024, 5, false, 16, false, true)   \
-  X(1024, 3, false, 16, false, true)
+#define APSS_CX_VARIANTS(X)                   \
+  X(512, 5, false, 16, false, false, false)   \
+  X(512, 4, false, 16, false, false, false)   \
+  X(512, 3, false, 16, false, false, false)   \
+  X(512, 2, false, 16, false, false, false)   \
+  X(512, 5, true, 16, false, false, false)    \
+  X(512, 4, true, 16, false, false, false)    \
+  X(512, 3, true, 16, false, false, false)    \
+  X(512, 2, true, 16, false, false, false)    \
+  X(512, 5, true, 16, false, false, true)     \
+  X(512, 4, false, 8, false, false, false)    \
+  X(512, 5, false, 16, true, false, false)    \
+  X(512, 5, false, 16, false, true, false)    \
+  X(512, 5, false, 16, true, true, false)     \
+  X(1024, 5, false, 16, false, false, false)  \
+  X(1024, 3, false, 16, false, false, false)  \
+  X(1024, 5, false, 16, true, false, false)   \
+  X(1024, 3, false, 16, true, false, false)   \
+  X(1024, 5, false, 16, false, true, false)   \
+  X(1024, 3, false, 16, false, true, false)
 
 struct CxVariant {
   int block, u;
   bool shard;
   int chunk;
   bool vrows, sgn;
+  bool longpf;  // prefetched long-segment sweeps: the sparse half of a handle with a dense-head block
 };
 
 bool cx_variant_exists(const CxVariant &v) {
-#define X(B, U, SH, CH, VR, SG) \
-  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG) return true;
+#define X(B, U, SH, CH, VR, SG, LP) \
+  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG && v.longpf == LP) return true;
   APSS_CX_VARIANTS(X)
 #undef X
   return false;
@@ -694,12 +697,12 @@ bool cx_variant_exists(const CxVariant &v) {
 
 int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
   const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
-#define X(B, U, SH, CH, VR, SG)                                                                              \
-  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG) {          \
-    hipLaunchKernelGGL((k_probe_coarse<B, U, (B <= 512 ? 128 : 256), (B <= 512 ? 512 : 1024), SH, CH, VR, SG>), grid, dim3(B), 0, \
-                       h->stream, a);                                                                        \
-    HIPCHK(h, hipGetLastError());                                                                            \
-    return APSS_OK;                                                                                          \
+#define X(B, U, SH, CH, VR, SG, LP)                                                                                        \
+  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG && v.longpf == LP) {      \
+    hipLaunchKernelGGL((k_probe_coarse<B, U, (B <= 512 ? 128 : 256), (B <= 512 ? 512 : 1024), SH, CH, VR, SG, LP>), grid, dim3(B), 0, \
+                       h->stream, a);                                                                                      \
+    HIPCHK(h, hipGetLastError());                                                                                          \
+    return APSS_OK;                                                                                                        \
   }
   APSS_CX_VARIANTS(X)
 #undef X
@@ -937,6 +940,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     if (cxv.vrows || cxv.sgn) u = cxv.block == 1024 ? u : 5;
     if (dbg.chunk8) u = 4;
     if (dbg.window && cxv.block == 512 && !cxv.vrows && !cxv.sgn) u = dbg.window;
+    if (hybrid_wanted && !dbg.window) {  // the skewed tail of a handle with a dense-head block: full window, prefetched long sweeps
+      u = 5;
+      cxv.longpf = true;
+    }
     cxv.u = u;
     if (!cx_variant_exists(cxv)) return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
   }

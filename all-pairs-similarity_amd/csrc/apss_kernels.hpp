@@ -132,13 +132,14 @@ __global__ void k_ingest_count(IngestArgs a) {
     a.row_keep[row] = admit ? 1 : 0;
     a.row_cnt[row] = admit ? cnt : 0;
     a.row_inv[row] = inv;
-    // the shard rule's scale: |x_g| / |x| (x_g = the row restricted to this handle's term range), rounded up a hair so
-    // that it only ever lowers a threshold; 1 on a handle that holds the whole term space
-    a.row_sub[row] = full > 0.f ? fminf(1.0f, sqrtf(sub / full) * 1.000001f) : 0.f;
+    // the shard rule's scale: |x_g| / |x| (x_g = the row restricted to this handle's term range), rounded DOWN a hair: as a
+    // factor of a threshold and as a divisor of a weight that errs on the side of reporting more
+    a.row_sub[row] = full > 0.f ? fminf(1.0f, sqrtf(sub / full)) * 0.999999f : 0.f;
     if (bad) atomicOr(&sh[0], bad);
     if (admit) {
       atomicMax(&sh[1], (unsigned)cnt);         // longest kept row: picks the probe kernel
-      atomicMax(&sh[2], __float_as_uint(sub));  // largest squared L2 norm of a kept row (fixed-point range)
+      atomicMax(&sh[2], __float_as_uint(full));  // largest squared L2 norm of a row (fixed-point range: a shard's
+                                                 // normalised partial p_g / (r_q r_c) is bounded by |q||c|, like a whole score)
       if (cnt > 0) atomicAdd(&sh[3], 1u);       // rows with at least one kept entry
     }
   }
@@ -266,6 +267,8 @@ struct BuildArgs {
   int32_t coarse_shift;           // 1: the slot field holds slot * 2, the byte offset of the 16-bit accumulator (tiles <= 32768 rows)
   int32_t seg_align;              // postings per aligned unit (kSegAlign / kSegAlignC)
   const uint32_t *erow;           // store row of every entry (LDS build)
+  const float *row_scale;         // shard rule (coarse rendering): row r's weights are stored divided by row_scale[r] = |x_g| / |x|,
+                                  //   so that the filter's threshold does not depend on the candidate (null: as they are)
 };
 
 // one wave per row: coalesced reads of the row's entries
@@ -324,7 +327,8 @@ __global__ void k_tile_scatter(BuildArgs a) {
     const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(&sg[t]), 1ull << 32);
     const uint32_t pos = (uint32_t)old + (uint32_t)(old >> 32);
     if (a.coarse) {
-      a.post_c[pbase + pos] = pack_coarse(local << a.coarse_shift, a.val[k]);
+      const float sc = a.row_scale ? a.row_scale[row] : 1.0f;
+      a.post_c[pbase + pos] = pack_coarse(local << a.coarse_shift, sc > 0.f ? a.val[k] / sc : a.val[k]);
     } else {
       Posting p;
       p.slot = local;
@@ -400,7 +404,8 @@ __global__ __launch_bounds__(1024) void k_tile_scatter_lds(BuildArgs a, int64_t 
       if ((uint32_t)(t[j] - lo) < span) {
         const uint32_t local = er[j] - (uint32_t)rA;
         if (a.coarse) {
-          a.post_c[pbase + pos[j]] = pack_coarse(local << a.coarse_shift, vv[j]);
+          const float sc = a.row_scale ? a.row_scale[er[j]] : 1.0f;
+          a.post_c[pbase + pos[j]] = pack_coarse(local << a.coarse_shift, sc > 0.f ? vv[j] / sc : vv[j]);
         } else {
           Posting p;
           p.slot = local;
@@ -1259,7 +1264,7 @@ __global__ void k_vrow_fill(const int64_t *rowptr, int64_t n, int part, const in
 // most one unit per shared term; the host picks S so that S*|q||c| + min(nnz_q, nnz_c) stays below 2^16 (no carry).
 // __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
 // sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.
-template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false, bool SIGNED = false>
+template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false, bool SIGNED = false, bool LONGPF = false>
 __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   constexpr bool SLOT2 = BLOCK <= 512;    // tiles of <= 32768 rows: the posting's slot field is slot * 2 (see pack_coarse)
@@ -1271,6 +1276,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // STATIC LDS (sized for the largest tile this instantiation serves): the compiler then knows every LDS address and
   // folds the array bases into the instructions' offset fields; through a dynamic `extern __shared__` base every LDS
   // access of the hot loop paid a VALU add of the (link-time) base.
+  constexpr int kLongLen = kLongLenW;  // (128 / 512 for the prefetched sweeps measured slower: 710 / 884 vs 614 ms, C3 with Zipf(1))
   constexpr int CBMAX = BLOCK <= 512 ? 32768 : 65536;
   __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / 2 + kWave];  // two u16 accumulators per word (+ slack)
   __shared__ uint2 items[NW * WIN];        // [NW][WIN] {byte offset of the chunk's first posting, weight bits}
@@ -1300,7 +1306,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const uint32_t lo = (uint32_t)(ln % LPC);  // this lane handles postings 2*lo and 2*lo + 1 of its chunk
   uint2 *wl = items + wv * WIN;
   const float cxs = a.cx_scale;
-  const float tile_scale = SHARD ? a.tile_scale[tile] : 1.0f;  // shard mode: min positive sub-norm of the tile's rows
 
   const int64_t qbase = a.q_rowptr[q0], qend = a.q_rowptr[q1];
   const int64_t pbase = a.tile_post_base[tile], pend = a.tile_post_base[tile + 1];
@@ -1321,7 +1326,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   uint32_t my_cands = 0;    // first touches of the sweeps (divergent control flow: per lane)
   uint32_t n_long_next = 0;
 
-  struct RowExt { int qb; int nnz; int q; bool last; };  // part extent, its query, is it the query's last part
+  // part extent, its query, is it the query's last part; shard rule: 1 / (|q_g| / |q|), the query's half of the normalisation
+  struct RowExt { int qb; int nnz; int q; bool last; float inv_qs; };
   struct TermW { uint32_t term; float w; bool valid; };
   struct Seg { uint32_t s, len; float w; };
   struct WaveWork {
@@ -1348,6 +1354,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     }
     r.qb = (int)(b - qbase);
     r.nnz = v < v1 ? (int)(e - b) : 0;
+    r.inv_qs = 1.0f;
+    if (SHARD) {
+      const float qsv = a.q_scale[r.q];
+      r.inv_qs = qsv > 0.f ? 1.0f / qsv : 0.f;
+    }
     return r;
   };
   auto load_I = [&](const RowExt &r) {
@@ -1369,11 +1380,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   auto flatten = [&](WaveWork &f, const Seg &g, const RowExt &r, int li) {
     uint32_t len = g.len;
     my_visits += len;
-    if (len > (uint32_t)kLongLenW) {
+    if (len > (uint32_t)kLongLen) {
       const uint32_t k = atomicAdd(&ctr[li], 1u);
       if (k < (uint32_t)LONGCAP) {
         longs[li * LONGCAP + k] = make_uint2(g.s, len);
-        long_w[li * LONGCAP + k] = g.w;
+        long_w[li * LONGCAP + k] = g.w * (SHARD ? r.inv_qs : 1.0f);
         len = 0;
       }
     }
@@ -1383,10 +1394,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     f.s = g.s;
     f.len = len;
     f.excl = excl;
-    f.w = g.w;
+    f.w = g.w * (SHARD ? r.inv_qs : 1.0f);
     f.tw = wv < r.nnz ? (r.nnz - wv + NW - 1) / NW : 0;
     f.totch = __builtin_amdgcn_readlane((int)incl, kWave - 1);
-    const uint32_t wbits = __float_as_uint(cxs * g.w);
+    const uint32_t wbits = __float_as_uint(cxs * f.w);
     auto put = [&](const uint32_t k) {
       if (k < nch && excl + k < (uint32_t)WIN)
         wl[excl + k] = make_uint2((g.s + k * CH) * 4u, wbits);  // {byte offset of the chunk's first posting, weight bits}
@@ -1437,11 +1448,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     const int par = (v - v0) & 1;
     const int q = cur.q;
     // coarse threshold: products are rounded UP (add16), so a coarse sum is never below S * sum(q_i * fp16(c_i)); the 2
-    // units cover the fp32 rounding of the scaled query weight.  Shard mode: the candidate rule p_g >= theta |q_g| |c_g|
-    // with the tile's smallest |c_g| in the hot loop and the candidate's own |c_g| on the survivors.
-    const float qs = SHARD ? a.q_scale[q] : 1.0f;
+    // units cover the fp32 rounding of the scaled query weight.  Shard rule (p_g >= theta r_q r_c, r_x = |x_g| / |x|): the
+    // postings hold c_i / r_c (index build) and the query weights are divided by r_q (flatten), so a sum is
+    // p_g / (r_q r_c) and the threshold is the same theta for every query and candidate.
     constexpr int slack = 2;
-    const int thr_c = (SHARD ? (int)floorf(a.cx_theta * qs * tile_scale) : (int)a.cx_theta) - slack;
+    const int thr_c = (int)a.cx_theta - slack;
     const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
 
     const RowExt R4 = load_R(v + 4);
@@ -1561,23 +1572,61 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       }
     }
     const uint32_t n_long = min(n_long_next, (uint32_t)LONGCAP);
-    for (uint32_t j = 0; j < n_long; ++j) {
-      const uint2 sgm = longs[l3 * LONGCAP + j];
-      const float wq_ = cxs * long_w[l3 * LONGCAP + j];
-      // two postings (8 B) per lane and load, two loads in flight per lane
-      uint32_t k = 2u * tid;
-      for (; k + 2u * BLOCK < sgm.y; k += 4u * BLOCK) {
-        const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-        const apss_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2u * BLOCK) * 4u, 0, 0);
-        visit(a0.x, wq_);
-        if (k + 1u < sgm.y) visit(a0.y, wq_);
-        visit(a1.x, wq_);
-        if (k + 2u * BLOCK + 1u < sgm.y) visit(a1.y, wq_);
+    if constexpr (LONGPF) {
+      // LONGPF: the instantiation for the sparse half of a handle with a dense-head block -- a skewed tail, a dozen long
+      // segments per round.  They are swept by the whole workgroup, two postings (8 B) per lane and pass, and the first
+      // pass of the NEXT TWO segments is requested before the current one is added: a segment's load -> atomic -> test
+      // chain otherwise runs start to finish before the next begins (a round then costs n_long memory round trips:
+      // C3 with Zipf(1) terms, 753 -> 615 ms).  A zero word is no posting (padding; out-of-range reads return 0).
+      // (Its own instantiation: with no long segment in sight this code measured 7 - 10 % slower, uniform C3 and term shards.)
+      if (n_long > 0) {
+        // the workgroup splits into LG groups of BLOCK / LG threads; group g sweeps segments g, g + LG, ...: a typical long
+        // segment (a few hundred postings) fills a quarter of the workgroup, not all of it
+        constexpr uint32_t LG = 4, GT = BLOCK / LG, PASS = 2u * GT;
+        const uint32_t grp = (uint32_t)tid / GT, gt = (uint32_t)tid % GT;
+        auto first_pass = [&](const uint32_t i) {
+          const uint32_t j = i * LG + grp;
+          const uint2 sg = longs[l3 * LONGCAP + min(j, n_long - 1u)];
+          return __builtin_amdgcn_raw_buffer_load_b64(rs_po, j < n_long && 2u * gt < sg.y ? (sg.x + 2u * gt) * 4u : kOob, 0, 0);
+        };
+        apss_u32x2 n1 = first_pass(0), n2 = first_pass(1);
+        for (uint32_t i = 0; i * LG < n_long; ++i) {
+          const uint32_t j = min(i * LG + grp, n_long - 1u);
+          const bool mine = i * LG + grp < n_long;
+          const uint2 sgm = longs[l3 * LONGCAP + j];
+          const float wq_ = cxs * long_w[l3 * LONGCAP + j];
+          const apss_u32x2 cur = n1;
+          n1 = n2;
+          n2 = first_pass(i + 2u);
+          if (cur.x) visit(cur.x, wq_);
+          if (cur.y) visit(cur.y, wq_);
+          if (mine)
+            for (uint32_t k = 2u * gt + PASS; k < sgm.y; k += PASS) {  // further passes of a segment of > PASS postings
+              const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+              if (a0.x) visit(a0.x, wq_);
+              if (a0.y) visit(a0.y, wq_);
+            }
+        }
       }
-      for (; k < sgm.y; k += 2u * BLOCK) {
-        const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-        visit(a0.x, wq_);
-        if (k + 1u < sgm.y) visit(a0.y, wq_);
+    } else {
+      for (uint32_t j = 0; j < n_long; ++j) {
+        const uint2 sgm = longs[l3 * LONGCAP + j];
+        const float wq_ = cxs * long_w[l3 * LONGCAP + j];
+        // two postings (8 B) per lane and load, two loads in flight per lane
+        uint32_t k = 2u * tid;
+        for (; k + 2u * BLOCK < sgm.y; k += 4u * BLOCK) {
+          const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+          const apss_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2u * BLOCK) * 4u, 0, 0);
+          visit(a0.x, wq_);
+          if (k + 1u < sgm.y) visit(a0.y, wq_);
+          visit(a1.x, wq_);
+          if (k + 2u * BLOCK + 1u < sgm.y) visit(a1.y, wq_);
+        }
+        for (; k < sgm.y; k += 2u * BLOCK) {
+          const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+          visit(a0.x, wq_);
+          if (k + 1u < sgm.y) visit(a0.y, wq_);
+        }
       }
     }
     __syncthreads();
@@ -1598,8 +1647,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
           uint32_t c = 0;
           if (i < n_surv) {
             c = surv[i];
-            ok = a.ext_id[tile_row0 + c] != qext &&
-                 (!SHARD || (int)acc16[c] >= (int)floorf(a.cx_theta * qs * a.c_scale[tile_row0 + c]) - slack);
+            ok = a.ext_id[tile_row0 + c] != qext;
           }
           const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
           if (ok && o < a.res_cap) {
@@ -1614,8 +1662,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
           bool ok = false;
           if (i < cb) {
             const int64_t gs = tile_row0 + i;
-            ok = (int)acc16[i] >= max(thr_c, 1) && gs < a.n_rows && a.ext_id[gs] != qext &&
-                 (!SHARD || (int)acc16[i] >= (int)floorf(a.cx_theta * qs * a.c_scale[gs]) - slack);
+            ok = (int)acc16[i] >= max(thr_c, 1) && gs < a.n_rows && a.ext_id[gs] != qext;
           }
           const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
           if (ok && o < a.res_cap) {
