@@ -694,6 +694,7 @@ typedef struct {
   const double *values;
   const csc_t *csc;
   int64_t q_begin, q_end;
+  int32_t term_mod, term_rem; /* variant 2: this worker owns the dims with dim % term_mod == term_rem (0: all dims) */
   int64_t pairs, cands, visits;
   /* optional pair output (optcpu only) */
   vec_i64 *oq, *oc;
@@ -720,9 +721,10 @@ static void *job_run(void *arg) {
     int64_t nt = 0;
     for (int32_t k = 0; k < qn; ++k) {
       const int32_t d = qi[k];
+      if (j->term_mod > 0 && d % j->term_mod != j->term_rem) continue; /* another worker's dim (EPA:43) */
       const int64_t pb = j->csc->ptr[d], pe = j->csc->ptr[d + 1];
       j->visits += pe - pb;
-      if (j->variant == 0) {
+      if (j->variant == 0 || j->variant == 2) {
         for (int64_t p = pb; p < pe; ++p) {
           const int32_t c = j->csc->slot[p];
           if (stamp[c] == q) continue; /* scored once per (q, c): the intended de-dup of IWA:90 */
@@ -800,9 +802,20 @@ int64_t oracle_selfjoin_sample(int32_t variant, int32_t dim, double theta, int64
     jobs[t].indices = indices;
     jobs[t].values = values;
     jobs[t].csc = &csc;
-    /* interleaved blocks of 8 queries would balance better, contiguous is what an actor's mailbox does */
-    jobs[t].q_begin = q_begin + nq * t / n_threads;
-    jobs[t].q_end = q_begin + nq * (t + 1) / n_threads;
+    if (variant == 2) {
+      /* refcpu-T, the reference's own parallelism: worker t of T owns the dims with dim % T == t (EntryProxyActor.scala:
+       * 41-46), receives EVERY vector and recomputes the full dot product of every pair it reaches through one of its
+       * dims (IWA:92) -- a pair sharing dims of k workers is scored k times.  cand_pairs then counts scorings,
+       * duplicates included. */
+      jobs[t].q_begin = q_begin;
+      jobs[t].q_end = q_end;
+      jobs[t].term_mod = n_threads;
+      jobs[t].term_rem = t;
+    } else {
+      /* interleaved blocks of 8 queries would balance better, contiguous is what an actor's mailbox does */
+      jobs[t].q_begin = q_begin + nq * t / n_threads;
+      jobs[t].q_end = q_begin + nq * (t + 1) / n_threads;
+    }
     pthread_create(&th[t], NULL, job_run, &jobs[t]);
   }
   int64_t pairs = 0, cands = 0, vis = 0;

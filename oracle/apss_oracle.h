@@ -114,6 +114,10 @@ int64_t oracle_print_sparse_vector(int32_t size, int64_t nnz, const int32_t *ind
  *   variant 0 "refcpu": CSC posting lists + per-candidate hash-map dot product in double exactly as
  *             CU:98-117 does (two maps built per call), candidates de-duplicated per query.
  *   variant 1 "optcpu": CSC posting lists + dense double accumulator per query (fairness bracket).
+ *   variant 2 "refcpu-T": the reference's own parallelism -- n_threads workers, worker t owning the dims with
+ *              dim % n_threads == t (EntryProxyActor.scala:41-46), each seeing every query and recomputing the full
+ *              hash-map dot of every pair it reaches through one of its dims; *cand_pairs counts scorings (a pair that
+ *              shares dims of k workers is scored k times, IWA:105 "TODO: need to deduplicate").
  * Queries q_begin..q_end are split over n_threads pthreads.  Returns pairs >= theta found; *cand_pairs gets
  * the number of scored candidate pairs, *visits the posting visits, *seconds the wall time of the query
  * phase only (the CSC build is excluded).

@@ -210,3 +210,20 @@ def test_golden_fixtures_match_oracle(oracle):
         got = to_map(*w.index_data(np.arange(n), z["rowptr"], z["indices"], z["values"]))
         want = to_map(z["out_q"], z["out_c"], z["out_sim"])
         assert_same_pairs(got, want, theta, band=0, tol=1e-15)
+
+
+def test_cpu_baseline_term_modulo_workers_variant():
+    """variant 2 of the CPU baseline = the reference's own parallelism (T workers owning dim % T, every worker sees every
+    query and re-scores every pair it reaches, EntryProxyActor.scala:41-46 + IWA:92): the same posting visits as the
+    query-range variant, at least as many scorings (a pair sharing dims of k workers is scored k times), one worker = no
+    duplicates"""
+    from oracle import oracle
+    from apss import synth
+    n, dim = 3000, 800
+    rp, idx, val = synth.make_vectors(n, dim, 12, 0.0, seed=4)
+    a = oracle.selfjoin_sample(0, dim, 0.5, rp, idx, val, 0, 500, 3)
+    b = oracle.selfjoin_sample(2, dim, 0.5, rp, idx, val, 0, 500, 3)
+    c = oracle.selfjoin_sample(2, dim, 0.5, rp, idx, val, 0, 500, 1)
+    assert a["visits"] == b["visits"] == c["visits"]
+    assert b["cand_pairs"] >= a["cand_pairs"] == c["cand_pairs"] and b["pairs"] >= a["pairs"] == c["pairs"]
+    assert b["cand_pairs"] < 3 * a["cand_pairs"]
