@@ -96,6 +96,31 @@ def test_c3_shape_zipf1_auto_policy(engine, oracle):
     assert_same_pairs({k: v for k, v in got.items() if k[0] < sample}, want, theta)
 
 
+def test_c5_power_law_reduced(engine, oracle):
+    """BASELINE.json configs[4] "power-law" at reduced N: dim = 1M (global-atomic index build, 31 term ranges), nnz = 200,
+    Zipf(1), theta = 0.9, N = 40k.  The library takes the dense-head block by itself; result set against the plain path on
+    the whole batch and against the oracle on a query sample; a frozen-index query batch afterwards (outside batch:
+    the square form of the contraction)"""
+    cfg, rp, idx, val = synth.make_config("c5z", n=40_000, device="cuda")
+    dim, theta, n = cfg["dim"], cfg["theta"], cfg["n"]
+    assert dim == 1_000_000 and cfg["nnz"] == 200
+    with engine.ApssIndex(dim, theta) as ix:
+        got = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
+        st = ix.stats()
+        assert st["head_terms"] in (64, 128, 256) and st["head_pairs"] > 0.9 * n * (n - 1), st
+        b0, b1 = 5000, 5600
+        sl = slice(rp[b0], rp[b1])
+        gq = to_map(*ix.query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl]))
+    ref, st0 = _join(engine, dim, theta, rp, idx, val, head_terms=-1)
+    assert st0["head_terms"] == 0 and ref.keys() == got.keys() and len(got) > 1000
+    assert max(abs(got[k] - ref[k]) for k in got) <= 2e-6
+    assert {k for k in gq} == {k for k in got if b0 <= k[0] < b1}
+    sample = 400
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val, 0, sample))
+    assert len(want) > 5
+    assert_same_pairs({k: v for k, v in got.items() if k[0] < sample}, want, theta)
+
+
 def test_streaming_batches_and_frozen_queries(engine, oracle):
     """the IndexData handler batch after batch (IndexingWorkerActor.scala:123-137) on a handle whose block is chosen at
     the first batch, then re-evaluated when the store has doubled; then frozen-index queries of a few vectors (the
