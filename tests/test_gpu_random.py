@@ -96,3 +96,27 @@ def test_single_vector_messages_wait_in_the_tail(oracle, head):
         assert_same_pairs(got, want, theta)
         full = to_map(*oracle.selfjoin_pairs(dim, theta, rp[:r + 1], idx[:rp[r]], val[:rp[r]]))
         assert_same_pairs(to_map(*ix.self_join()), full, theta)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_streams_with_a_forced_head_block(oracle, seed, monkeypatch):
+    """the same randomised streams (ragged rows: empty, single-term, long; duplicate ids; several batches; thresholds from
+    0.05 to 0.9) with the dense-head block forced on: rows without a head entry, rows with nothing BUT head entries (tail
+    ratio 0), dims smaller than the block (the block is refused), batches that wait in the tail, the no_tail hook"""
+    from apss.engine import ApssIndex
+    if seed % 4 == 3:
+        monkeypatch.setenv("APSS_DEBUG", "no_tail")
+    rng = np.random.default_rng(5000 + seed)
+    dim, theta, ids, rp, idx, val, cuts = _random_case(rng)
+    kh = [64, 128, 256][seed % 3]
+    w = oracle.Worker(dim, theta)
+    with ApssIndex(dim, theta, tile_rows=int(rng.choice([64, 1024, 0])), head_terms=kh) as ix:
+        for b0, b1 in zip(cuts[:-1], cuts[1:]):
+            sl = slice(rp[b0], rp[b1])
+            args = (ids[b0:b1], rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])
+            want = to_map(*w.index_data(*args))
+            got = to_map(*ix.insert_and_query(*args))
+            assert_same_pairs(got, want, theta)
+        assert ix.size()[0] == len(ids)
+        st = ix.stats()
+        assert st["head_terms"] in (0, min(kh, dim)) or st["head_terms"] <= kh
