@@ -46,6 +46,7 @@ struct DebugCfg {
   int chunks = 0;              // chunks=N       query chunks per tile (grid shape)
   int tiles_per_launch = 0;    // tiles_per_launch=N
   bool no_tail = false;        // no_tail        every insert extends the tile index at once (no tail of waiting rows)
+  bool no_acc8 = false;        // no_acc8        term shards keep 16-bit accumulators over 32768-row tiles
 };
 
 DebugCfg parse_debug_env() {
@@ -74,6 +75,7 @@ DebugCfg parse_debug_env() {
     else if (key == "chunks") d.chunks = val;
     else if (key == "tiles_per_launch") d.tiles_per_launch = val;
     else if (key == "no_tail") d.no_tail = val != 0;
+    else if (key == "no_acc8") d.no_acc8 = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -426,6 +428,17 @@ int32_t ensure_exact_index(apss_handle *h) {
   return APSS_OK;
 }
 
+// 8-bit accumulator scale of a term shard: the largest S = 2^k <= 2^7 with  S * max|q||c| * 1.0005 + shared terms < 2^8  (no
+// carry into the neighbour's byte), taken only while the threshold in units stays well above what a chance pair collects
+// (one unit of round-up per shared term).  0: not usable.
+double acc8_scale(double bound, double shared, double theta) {
+  for (int k = 7; k >= 5; --k) {
+    const double S = std::ldexp(1.0, k);
+    if (bound * 1.0005 * S < 255.0 - shared && std::floor(theta * S * (1.0 - 1.0 / 2048 - 1e-6)) - 2 >= 12.0) return S;
+  }
+  return 0.0;
+}
+
 // ---- dense-head block (apss_head.hpp) ----
 constexpr int64_t kTailMaxRows = 4096;   // rows that may wait outside the tile index (scored pair by pair by k_tail_score)
 constexpr int64_t kTailMaxBatch = 256;   // a batch larger than this extends the index right away
@@ -635,6 +648,11 @@ int32_t build_index(apss_handle *h, int64_t row0) {
       // 1024-thread workgroup per CU wins (C5 shape at N=2M: 647 vs 790 ms); at C3 (33) two workgroups per CU win.
       const double seg32 = 32768.0 * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;
       h->cx.cb = seg32 < 16.0 && !h->sharded && !h->head_k ? 65536 : 32768;  // (the 1024-thread kernel has no shard variant)
+      // a term shard's rounds are thin (1/T of every query's terms): 8-bit accumulators hold 65536 candidates in the same
+      // 64 KB, i.e. half the rounds at the same two workgroups per CU -- when the norms and row lengths leave room for them
+      if (h->sharded && !h->dbgcfg.no_acc8 &&
+          acc8_scale((double)h->store_max_norm2 * 1.0001 + 1e-6, (double)h->store_max_nnz, h->cfg.theta) > 0)
+        h->cx.cb = 65536;
     }
     APSS_TRY(build_tiles(h, h->cx, row0));
     h->st.build_ms += h->cx.build_ms;
@@ -658,26 +676,30 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
 
 // ---- the filter kernel's instantiations: (threads, register-window steps, shard rule, postings per chunk, virtual
 // rows, signed weights).  One table, one lookup: a combination that is not listed is an error, never another kernel.
-#define APSS_CX_VARIANTS(X)                   \
-  X(512, 5, false, 16, false, false, false)   \
-  X(512, 4, false, 16, false, false, false)   \
-  X(512, 3, false, 16, false, false, false)   \
-  X(512, 2, false, 16, false, false, false)   \
-  X(512, 5, true, 16, false, false, false)    \
-  X(512, 4, true, 16, false, false, false)    \
-  X(512, 3, true, 16, false, false, false)    \
-  X(512, 2, true, 16, false, false, false)    \
-  X(512, 5, true, 16, false, false, true)     \
-  X(512, 4, false, 8, false, false, false)    \
-  X(512, 5, false, 16, true, false, false)    \
-  X(512, 5, false, 16, false, true, false)    \
-  X(512, 5, false, 16, true, true, false)     \
-  X(1024, 5, false, 16, false, false, false)  \
-  X(1024, 3, false, 16, false, false, false)  \
-  X(1024, 5, false, 16, true, false, false)   \
-  X(1024, 3, false, 16, true, false, false)   \
-  X(1024, 5, false, 16, false, true, false)   \
-  X(1024, 3, false, 16, false, true, false)
+#define APSS_CX_VARIANTS(X)                          \
+  X(512, 5, false, 16, false, false, false, false)   \
+  X(512, 4, false, 16, false, false, false, false)   \
+  X(512, 3, false, 16, false, false, false, false)   \
+  X(512, 2, false, 16, false, false, false, false)   \
+  X(512, 5, true, 16, false, false, false, false)    \
+  X(512, 4, true, 16, false, false, false, false)    \
+  X(512, 3, true, 16, false, false, false, false)    \
+  X(512, 2, true, 16, false, false, false, false)    \
+  X(512, 5, true, 16, false, false, false, true)     \
+  X(512, 4, true, 16, false, false, false, true)     \
+  X(512, 3, true, 16, false, false, false, true)     \
+  X(512, 2, true, 16, false, false, false, true)     \
+  X(512, 5, true, 16, false, false, true, false)     \
+  X(512, 4, false, 8, false, false, false, false)    \
+  X(512, 5, false, 16, true, false, false, false)    \
+  X(512, 5, false, 16, false, true, false, false)    \
+  X(512, 5, false, 16, true, true, false, false)     \
+  X(1024, 5, false, 16, false, false, false, false)  \
+  X(1024, 3, false, 16, false, false, false, false)  \
+  X(1024, 5, false, 16, true, false, false, false)   \
+  X(1024, 3, false, 16, true, false, false, false)   \
+  X(1024, 5, false, 16, false, true, false, false)   \
+  X(1024, 3, false, 16, false, true, false, false)
 
 struct CxVariant {
   int block, u;
@@ -685,11 +707,14 @@ struct CxVariant {
   int chunk;
   bool vrows, sgn;
   bool longpf;  // prefetched long-segment sweeps: the sparse half of a handle with a dense-head block
+  bool acc8;    // 8-bit accumulators over 65536-row tiles: thin rounds of a term shard
 };
 
 bool cx_variant_exists(const CxVariant &v) {
-#define X(B, U, SH, CH, VR, SG, LP) \
-  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG && v.longpf == LP) return true;
+#define X(B, U, SH, CH, VR, SG, LP, A8)                                                                                 \
+  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG && v.longpf == LP &&   \
+      v.acc8 == A8)                                                                                                     \
+    return true;
   APSS_CX_VARIANTS(X)
 #undef X
   return false;
@@ -697,10 +722,11 @@ bool cx_variant_exists(const CxVariant &v) {
 
 int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
   const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
-#define X(B, U, SH, CH, VR, SG, LP)                                                                                        \
-  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG && v.longpf == LP) {      \
-    hipLaunchKernelGGL((k_probe_coarse<B, U, (B <= 512 ? 128 : 256), (B <= 512 ? 512 : 1024), SH, CH, VR, SG, LP>), grid, dim3(B), 0, \
-                       h->stream, a);                                                                                      \
+#define X(B, U, SH, CH, VR, SG, LP, A8)                                                                                    \
+  if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG && v.longpf == LP &&      \
+      v.acc8 == A8) {                                                                                                      \
+    hipLaunchKernelGGL((k_probe_coarse<B, U, (B <= 512 ? 128 : 256), (B <= 512 ? 512 : 1024), SH, CH, VR, SG, LP, A8>), grid, dim3(B), \
+                       0, h->stream, a);                                                                                   \
     HIPCHK(h, hipGetLastError());                                                                                          \
     return APSS_OK;                                                                                                        \
   }
@@ -840,8 +866,23 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const bool shard_rule = h->sharded || hybrid_wanted;
   const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !shard_rule &&
                          (h->cx.cb <= 32768 || q_max_nnz <= 512) && !dbg.chunk8 && !dbg.window;
-  const bool coarse_path = h->use_coarse && (mode == 0 || cx_signed) && cx_selective && cx_fp16_ok && !forced_general && nq < (1LL << 30) &&
-                           !(shard_rule && h->cx.cb > 32768) &&
+  // term shards over 65536-row tiles: the 8-bit filter, if this call's norms and row lengths leave room for its sums
+  const bool big_shard_tiles = h->sharded && h->cx.cb > 32768;
+  const double a8_scale = big_shard_tiles && mode == 0 ? acc8_scale(bound, cx_shared, theta) : 0.0;
+  if (big_shard_tiles && !(a8_scale > 0)) {
+    // not this time (a long row, a large norm, signed weights): back to 16-bit accumulators over 32768-row tiles, for good
+    h->cx.cb = 32768;
+    h->cx.n_tiles = 0;
+    h->dbgcfg.no_acc8 = true;
+    APSS_TRY(build_index(h, 0));
+    return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_slot_first, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
+  }
+  if (a8_scale > 0) {
+    cx_scale = a8_scale;
+  }
+  const double cx_theta_used = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
+  const bool coarse_path = h->use_coarse && (mode == 0 || cx_signed) && (cx_selective || a8_scale > 0) && cx_fp16_ok && !forced_general && nq < (1LL << 30) &&
+                           !(shard_rule && h->cx.cb > 32768 && !(a8_scale > 0)) &&
                            (q_max_nnz <= 512 || !shard_rule) &&
                            !dbg.exact_accum && cx_scale > 0 && cx_theta < 65000.0 && (shard_rule || cx_theta - 2 >= 1.0) &&
                            std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
@@ -888,7 +929,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.theta = (float)theta;
   a.counters = h->counters.p;
   a.cx_scale = (float)cx_scale;
-  a.cx_theta = (float)cx_theta;
+  a.cx_theta = (float)cx_theta_used;
 
   apss_handle::IndexSet &ix = coarse_path ? h->cx : h->ex;
   if (!coarse_path) APSS_TRY(ensure_exact_index(h));
@@ -922,7 +963,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // (term shards: 1/T of a query's terms; sparse regimes: short segments) take a short window
   CxVariant cxv{};
   if (coarse_path) {
-    cxv.block = h->cx.cb > 32768 ? 1024 : 512;
+    cxv.acc8 = a8_scale > 0;
+    cxv.block = h->cx.cb > 32768 && !cxv.acc8 ? 1024 : 512;
     cxv.shard = shard_rule;
     cxv.chunk = dbg.chunk8 ? 8 : 16;
     cxv.vrows = q_max_nnz > 512;

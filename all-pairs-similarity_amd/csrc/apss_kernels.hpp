@@ -1264,10 +1264,18 @@ __global__ void k_vrow_fill(const int64_t *rowptr, int64_t n, int part, const in
 // most one unit per shared term; the host picks S so that S*|q||c| + min(nnz_q, nnz_c) stays below 2^16 (no carry).
 // __launch_bounds__(512, 4): two workgroups of 8 waves per CU = 4 waves per SIMD = at most 128 VGPRs.  The kernel
 // sits right at that edge; without the bound a small edit tipped it to 130 VGPRs = one workgroup per CU = 1.6x slower.
-template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false, bool SIGNED = false, bool LONGPF = false>
+template <int BLOCK, int U, int LONGCAP, int SURVCAP, bool SHARD, int CHUNK = 16, bool VROWS = false, bool SIGNED = false, bool LONGPF = false,
+          bool ACC8 = false>
 __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_coarse(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
-  constexpr bool SLOT2 = BLOCK <= 512;    // tiles of <= 32768 rows: the posting's slot field is slot * 2 (see pack_coarse)
+  // SLOT2: the posting's slot field is the LDS BYTE OFFSET of the candidate's accumulator: slot * 2 for 16-bit accumulators
+  // (tiles of <= 32768 rows, see pack_coarse), the slot itself for 8-bit ones (ACC8: 65536 rows in the same 64 KB).
+  // ACC8 serves thin rounds (term shards: a dozen terms per row and shard): twice the candidates per round at the same two
+  // workgroups per CU, i.e. half the rounds.  Sums are S * (normalised partial) + one unit per shared term, S <= 2^7; the host
+  // picks S so that they stay below 2^8 (no carry into the neighbour's byte).
+  constexpr bool SLOT2 = BLOCK <= 512;
+  constexpr uint32_t ABITS = ACC8 ? 8u : 16u;  // accumulator width
+  static_assert(!ACC8 || BLOCK <= 512, "8-bit accumulators: the 512-thread kernel only");
   constexpr int CH = CHUNK;              // postings per chunk: LPC lanes x 2 postings (8 B per lane)
   constexpr int LPC = CH / 2;            // lanes per chunk
   constexpr int GPW = kWave / LPC;       // chunks per wave step
@@ -1277,8 +1285,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // folds the array bases into the instructions' offset fields; through a dynamic `extern __shared__` base every LDS
   // access of the hot loop paid a VALU add of the (link-time) base.
   constexpr int kLongLen = kLongLenW;  // (128 / 512 for the prefetched sweeps measured slower: 710 / 884 vs 614 ms, C3 with Zipf(1))
-  constexpr int CBMAX = BLOCK <= 512 ? 32768 : 65536;
-  __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / 2 + kWave];  // two u16 accumulators per word (+ slack)
+  constexpr int CBMAX = BLOCK <= 512 && !ACC8 ? 32768 : 65536;
+  constexpr int APW = 32 / (int)ABITS;  // accumulators per LDS word
+  __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / APW + kWave];  // two u16 / four u8 accumulators per word (+ slack)
   __shared__ uint2 items[NW * WIN];        // [NW][WIN] {byte offset of the chunk's first posting, weight bits}
   __shared__ uint2 longs[3 * LONGCAP];     // [3][LONGCAP]
   __shared__ float long_w[3 * LONGCAP];    // [3][LONGCAP]
@@ -1319,7 +1328,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.post_c + pbase), 0, (int)((pend - pbase) * 4), 0x00020000);
   constexpr uint32_t kOob = 0xfffffff0u;
 
-  for (int i = tid * 4; i < cb / 2 + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid * 4; i < cb / APW + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 16) ctr[tid] = 0;
   unsigned long long my_visits = 0;
   uint32_t wave_cands = 0;  // first touches of the register window (uniform control flow: ballots on the scalar unit)
@@ -1465,7 +1474,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     };
     // one coarse posting: 16-bit add into the candidate's half of its word; the returning atomic gives the old WORD
     // (the half is extracted later, so that the round's atomics are all in flight before the first wait)
-    auto slot_of = [&](const uint32_t pcw) { return SLOT2 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu; };
+    auto slot_of = [&](const uint32_t pcw) { return SLOT2 && !ACC8 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu; };
     // the product of one posting, rounded up: floor(x) + 1 is never below x and >= 1, so that a touch always shows
     // SIGNED (weights of either sign, theta > 0): only the positive products count and a negative one adds a single
     // unit, so a sum is an upper bound of S * score that still grows with every touch -- sound for a filter (a pair
@@ -1481,8 +1490,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));
     };
     auto half_of = [&](const uint32_t old_word, const uint32_t pcw) {
-      // SLOT2: bit 1 of the slot field selects the half; v_bfe_u32 takes the offset modulo 32 and bit 0 is clear
-      return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, 16u) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
+      // SLOT2: the low bits of the byte offset select the field; v_bfe_u32 takes the offset modulo 32
+      return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, ABITS) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
     };
     auto visit = [&](const uint32_t pcw, const float wqs) {
       const uint32_t p = prod(pcw, wqs);
@@ -1640,7 +1649,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     const bool full_zero = cur.last && (multi || rescan || n_long > 0 || fl.x != 0);
     if ((n_surv > 0 && !rescan) || (cur.last && rescan)) {
       const int64_t qext = a.q_ext[q];
-      const unsigned short *acc16 = reinterpret_cast<const unsigned short *>(acc);
+      const unsigned short *acc16p = reinterpret_cast<const unsigned short *>(acc);
+      const unsigned char *acc8p = reinterpret_cast<const unsigned char *>(acc);
+      auto acc_at = [&](const int c) -> int { return ACC8 ? (int)acc8p[c] : (int)acc16p[c]; };
       if (!rescan) {
         for (uint32_t i = tid; i < (n_surv + kWave - 1) / kWave * kWave; i += BLOCK) {
           bool ok = false;
@@ -1653,7 +1664,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
           if (ok && o < a.res_cap) {
             a.res_q[o] = q;
             a.res_c[o] = (int32_t)(tile_row0 + c);
-            a.res_s[o] = (float)acc16[c] / cxs;  // coarse score, replaced by k_rescore
+            a.res_s[o] = (float)acc_at((int)c) / cxs;  // coarse score, replaced by k_rescore
           }
         }
       } else if (cur.last) {
@@ -1662,13 +1673,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
           bool ok = false;
           if (i < cb) {
             const int64_t gs = tile_row0 + i;
-            ok = (int)acc16[i] >= max(thr_c, 1) && gs < a.n_rows && a.ext_id[gs] != qext;
+            ok = acc_at(i) >= max(thr_c, 1) && gs < a.n_rows && a.ext_id[gs] != qext;
           }
           const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
           if (ok && o < a.res_cap) {
             a.res_q[o] = q;
             a.res_c[o] = (int32_t)(tile_row0 + i);
-            a.res_s[o] = (float)acc16[i] / cxs;
+            a.res_s[o] = (float)acc_at(i) / cxs;
           }
         }
       }
@@ -1676,13 +1687,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     }
 
     if (full_zero) {
-      for (int i = tid * 4; i < cb / 2; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = tid * 4; i < cb / APW; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
     } else if (cur.last) {
       unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // unconditional: an idle lane (zero word) clears slot 0, which is zero at the end of a query either way
-        if (SLOT2) {
+        if (SLOT2 && ACC8) {
+          smem_raw[w0.pc[u].x & 0xffffu] = 0;  // ds_write_b8
+          smem_raw[w0.pc[u].y & 0xffffu] = 0;
+        } else if (SLOT2) {
           *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].x & 0xffffu)) = 0;  // ds_write_b16
           *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].y & 0xffffu)) = 0;
         } else {

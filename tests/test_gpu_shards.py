@@ -134,3 +134,70 @@ def test_c4_full_size_eight_term_shards_on_one_gpu():
     assert len(out["probe_ms_per_shard"]) == 8 and out["max_abs_score_error"] <= 1e-5
     # the exchange stays small: a shard's candidate list is of the order of the true pairs, not of the touched pairs
     assert max(out["candidates_per_shard"]) < 4 * out["result_pairs"]
+
+
+@pytest.mark.parametrize("world,hook", [(4, None), (8, None), (8, "no_acc8"), (3, "window=2")])
+def test_term_shards_8bit_filter_matches_oracle(oracle, monkeypatch, world, hook):
+    """default tile size: a term shard whose norms and row lengths leave room runs the 8-bit filter over 65536-row tiles
+    (k_probe_coarse<.., ACC8>); same pairs as the oracle, as with the hook that keeps 16-bit accumulators"""
+    import torch
+    if hook:
+        monkeypatch.setenv("APSS_DEBUG", hook)
+    from apss.dist import HipShardEngine, join_shards_local, term_ranges
+    n, dim, nnz, theta = 70_000, 6000, 32, 0.7
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=17, dup_frac=0.05)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 3000
+    dev = torch.device("cuda", 0)
+    engines = [HipShardEngine(dim, theta, tr, dev) for tr in term_ranges(np.bincount(idx, minlength=dim), world)]
+    for e in engines:
+        e.load(rp, idx, val)
+    q, c, s, n_cand = join_shards_local(engines, n, theta)
+    assert_same_pairs(to_map(q, c, s), want, theta)
+    assert engines[0].stats["tiles"] == (2 if hook != "no_acc8" else 3)  # 65536-row tiles unless the hook forbids them
+    assert sum(e.stats["posting_visits"] for e in engines) == int(synth.workload_counts(dim, rp, idx)[1])
+    # the rule's own false candidates (two rows whose dominant term inside a shard coincides) dwarf the filter's: a small
+    # fraction of the pairs a shard touches either way
+    assert max(n_cand) < 0.05 * min(e.stats["candidate_pairs"] for e in engines)
+
+
+def test_8bit_shard_filter_falls_back_when_a_query_batch_does_not_fit(oracle):
+    """the store's rows fit the 8-bit sums, a later query batch does not (norm 12: even at 2^5 units per 1.0, S |q||c| would
+    carry into the neighbour's byte): the handle rebuilds its index for 16-bit accumulators and answers; exchange done by
+    hand as apss.dist does it"""
+    import torch
+    from apss.engine import ApssIndex
+    n, nq, dim, nnz, theta = 40_000, 300, 5000, 24, 9.0
+    rp, idx, val = synth.make_vectors(n + nq, dim, nnz, 0.0, seed=23, dup_frac=0.0)
+    # queries: scaled copies of stored rows (score = 12 x cosine)
+    qrows = np.arange(0, nq) * 7
+    q_rp = np.arange(0, (nq + 1) * nnz, nnz, dtype=np.int64)
+    q_idx = np.concatenate([idx[rp[r]:rp[r + 1]] for r in qrows])
+    q_val = np.concatenate([val[rp[r]:rp[r + 1]] for r in qrows]) * 12.0
+    e0 = int(rp[n])
+    w = oracle.Worker(dim, theta)
+    w.index_data(np.arange(n), rp[:n + 1], idx[:e0], val[:e0], build_only=True)
+    want = to_map(*w.index_data(np.arange(n, n + nq), q_rp, q_idx, q_val, query_only=True))
+    assert len(want) >= nq
+    dev = torch.device("cuda", 0)
+    shards = [ApssIndex(dim, theta, term_range=tr) for tr in ((0, 2500), (2500, 5000))]
+    keys, tiles_before = [], []
+    for ix in shards:
+        ix.insert(np.arange(n), rp[:n + 1], idx[:e0], val[:e0])
+        tiles_before.append(ix.stats()["tiles"])
+        qq, cc, _ = ix.query(np.arange(n, n + nq), q_rp, q_idx, q_val)
+        assert ix.stats()["tiles"] == 2  # rebuilt: 32768-row tiles
+        keys.append((qq - n) * n + cc)
+    assert tiles_before == [1, 1]  # 65536-row tiles while the 8-bit filter was in use
+    uniq = np.unique(np.concatenate(keys))
+    uq, uc = torch.from_numpy(uniq // n).to(dev).to(torch.int32), torch.from_numpy(uniq % n).to(dev).to(torch.int32)
+    total = torch.zeros(uniq.size, dtype=torch.float32, device=dev)
+    for ix in shards:
+        part = torch.empty_like(total)
+        ix.partial_scores_dev(uq, uc, part)
+        total += part
+    keep = (total >= theta).cpu().numpy()
+    got = {(int(a) + n, int(b)): float(v) for a, b, v in zip(uniq[keep] // n, uniq[keep] % n, total.cpu().numpy()[keep])}
+    assert_same_pairs(got, want, theta, band=1e-4, tol=1e-4)
+    for ix in shards:
+        ix.close()
