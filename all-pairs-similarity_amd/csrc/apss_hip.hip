@@ -47,6 +47,7 @@ struct DebugCfg {
   int tiles_per_launch = 0;    // tiles_per_launch=N
   bool no_tail = false;        // no_tail        every insert extends the tile index at once (no tail of waiting rows)
   bool no_acc8 = false;        // no_acc8        term shards keep 16-bit accumulators over 32768-row tiles
+  int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
 };
 
 DebugCfg parse_debug_env() {
@@ -76,6 +77,7 @@ DebugCfg parse_debug_env() {
     else if (key == "tiles_per_launch") d.tiles_per_launch = val;
     else if (key == "no_tail") d.no_tail = val != 0;
     else if (key == "no_acc8") d.no_acc8 = val != 0;
+    else if (key == "seg_align") d.seg_align = val;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -378,6 +380,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.erow = h->erow.p;
   b.row_scale = scaled && ix.coarse ? h->sub.p : nullptr;  // shard rule: postings normalised by |x_g| / |x| (k_probe_coarse)
   b.coarse_shift = ix.coarse && ix.cb <= 32768 ? 1 : 0;  // must agree with k_probe_coarse's SLOT2 (the 512-thread kernels)
+  b.coarse_wide = ix.coarse && ix.cb > 65536 ? 1 : 0;     // ... and with its WIDE (131072-row tiles)
   const int threads = 256;
   const int64_t blocks = ceil_div((h->idx_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
@@ -648,6 +651,11 @@ int32_t build_index(apss_handle *h, int64_t row0) {
       // 1024-thread workgroup per CU wins (C5 shape at N=2M: 647 vs 790 ms); at C3 (33) two workgroups per CU win.
       const double seg32 = 32768.0 * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;
       h->cx.cb = seg32 < 16.0 && !h->sharded && !h->head_k ? 65536 : 32768;  // (the 1024-thread kernel has no shard variant)
+      // sparser still (C5: 6.5): 131072-row tiles with 8-bit accumulators (k_probe_coarse<1024, .., ACC8>) when the norms and
+      // row lengths leave room for them: half the segment-descriptor look-ups and half the half-empty posting lines
+      if (h->cx.cb == 65536 && seg32 < 8.0 && h->nonneg && !h->dbgcfg.no_acc8 && h->store_max_nnz <= 512 &&
+          acc8_scale((double)h->store_max_norm2 * 1.0001 + 1e-6, (double)h->store_max_nnz, h->cfg.theta) > 0)
+        h->cx.cb = 131072;
       // a term shard's rounds are thin (1/T of every query's terms): 8-bit accumulators hold 65536 candidates in the same
       // 64 KB, i.e. half the rounds at the same two workgroups per CU -- when the norms and row lengths leave room for them
       if (h->sharded && !h->dbgcfg.no_acc8 &&
@@ -689,6 +697,10 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
   X(512, 4, true, 16, false, false, false, true)     \
   X(512, 3, true, 16, false, false, false, true)     \
   X(512, 2, true, 16, false, false, false, true)     \
+  X(512, 5, false, 16, false, false, false, true)    \
+  X(512, 4, false, 16, false, false, false, true)    \
+  X(512, 3, false, 16, false, false, false, true)    \
+  X(512, 2, false, 16, false, false, false, true)    \
   X(512, 5, true, 16, false, false, true, false)     \
   X(512, 4, false, 8, false, false, false, false)    \
   X(512, 5, false, 16, true, false, false, false)    \
@@ -699,7 +711,9 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
   X(1024, 5, false, 16, true, false, false, false)   \
   X(1024, 3, false, 16, true, false, false, false)   \
   X(1024, 5, false, 16, false, true, false, false)   \
-  X(1024, 3, false, 16, false, true, false, false)
+  X(1024, 3, false, 16, false, true, false, false)   \
+  X(1024, 5, false, 16, false, false, false, true)   \
+  X(1024, 3, false, 16, false, false, false, true)
 
 struct CxVariant {
   int block, u;
@@ -866,12 +880,14 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const bool shard_rule = h->sharded || hybrid_wanted;
   const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !shard_rule &&
                          (h->cx.cb <= 32768 || q_max_nnz <= 512) && !dbg.chunk8 && !dbg.window;
-  // term shards over 65536-row tiles: the 8-bit filter, if this call's norms and row lengths leave room for its sums
+  // 65536-row tiles (term shards; the sparse regime of a plain handle): the 8-bit filter -- 65536 candidates in 64 KB, two
+  // 512-thread workgroups per CU -- if this call's norms and row lengths leave room for its sums
   const bool big_shard_tiles = h->sharded && h->cx.cb > 32768;
-  const double a8_scale = big_shard_tiles && mode == 0 ? acc8_scale(bound, cx_shared, theta) : 0.0;
-  if (big_shard_tiles && !(a8_scale > 0)) {
-    // not this time (a long row, a large norm, signed weights): back to 16-bit accumulators over 32768-row tiles, for good
-    h->cx.cb = 32768;
+  const double a8_scale = h->cx.cb >= 65536 && mode == 0 && !h->head_k && q_max_nnz <= 512 && !dbg.no_acc8 && !dbg.chunk8
+                              ? acc8_scale(bound, cx_shared, theta) : 0.0;
+  if ((big_shard_tiles || h->cx.cb > 65536) && !(a8_scale > 0)) {
+    // not this time (a long row, a large norm, signed weights): back to 16-bit accumulators over smaller tiles, for good
+    h->cx.cb = h->sharded ? 32768 : 65536;
     h->cx.n_tiles = 0;
     h->dbgcfg.no_acc8 = true;
     APSS_TRY(build_index(h, 0));
@@ -964,7 +980,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   CxVariant cxv{};
   if (coarse_path) {
     cxv.acc8 = a8_scale > 0;
-    cxv.block = h->cx.cb > 32768 && !cxv.acc8 ? 1024 : 512;
+    cxv.block = h->cx.cb > 65536 || (h->cx.cb > 32768 && !cxv.acc8) ? 1024 : 512;
     cxv.shard = shard_rule;
     cxv.chunk = dbg.chunk8 ? 8 : 16;
     cxv.vrows = q_max_nnz > 512;
@@ -1387,7 +1403,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   h->ex.align = kSegAlign;
   h->cx.cb = std::min(2 * h->cb, 32768);
   if (h->dbgcfg.cx_tile) h->cx.cb = h->dbgcfg.cx_tile;  // experiment hook (multiple of 64, <= 65536)
-  h->cx.align = kSegAlignC;
+  h->cx.align = h->dbgcfg.seg_align == 16 ? 16 : kSegAlignC;
   h->cx.coarse = true;
   if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {
     g_create_error = "tile_rows must be a multiple of 64 in [64, 32768]";

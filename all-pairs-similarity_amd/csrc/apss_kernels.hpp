@@ -251,6 +251,12 @@ __device__ __forceinline__ uint32_t pack_coarse(uint32_t slot, float w) {
   return (slot & 0xffffu) | (max((uint32_t)__half_as_ushort(__float2half_rn(w)), 1u) << 16);
 }
 
+// wide coarse posting (tiles of up to 131072 rows, 8-bit accumulators): slot << 15 | fp16 weight without its sign bit
+// (weights are non-negative on this path); never the zero word either
+__device__ __forceinline__ uint32_t pack_coarse_wide(uint32_t slot, float w) {
+  return (slot << 15) | max((uint32_t)__half_as_ushort(__float2half_rn(w)) & 0x7fffu, 1u);
+}
+
 struct BuildArgs {
   const int64_t *rowptr;
   const int32_t *idx;             // term of every entry; an entry held by the dense-head block has kNoTerm here
@@ -266,6 +272,7 @@ struct BuildArgs {
   int32_t coarse;
   int32_t coarse_shift;           // 1: the slot field holds slot * 2, the byte offset of the 16-bit accumulator (tiles <= 32768 rows)
   int32_t seg_align;              // postings per aligned unit (kSegAlign / kSegAlignC)
+  int32_t coarse_wide;            // 1: pack_coarse_wide (17-bit slots)
   const uint32_t *erow;           // store row of every entry (LDS build)
   const float *row_scale;         // shard rule (coarse rendering): row r's weights are stored divided by row_scale[r] = |x_g| / |x|,
                                   //   so that the filter's threshold does not depend on the candidate (null: as they are)
@@ -328,7 +335,8 @@ __global__ void k_tile_scatter(BuildArgs a) {
     const uint32_t pos = (uint32_t)old + (uint32_t)(old >> 32);
     if (a.coarse) {
       const float sc = a.row_scale ? a.row_scale[row] : 1.0f;
-      a.post_c[pbase + pos] = pack_coarse(local << a.coarse_shift, sc > 0.f ? a.val[k] / sc : a.val[k]);
+      const float wv_ = sc > 0.f ? a.val[k] / sc : a.val[k];
+      a.post_c[pbase + pos] = a.coarse_wide ? pack_coarse_wide(local, wv_) : pack_coarse(local << a.coarse_shift, wv_);
     } else {
       Posting p;
       p.slot = local;
@@ -405,7 +413,8 @@ __global__ __launch_bounds__(1024) void k_tile_scatter_lds(BuildArgs a, int64_t 
         const uint32_t local = er[j] - (uint32_t)rA;
         if (a.coarse) {
           const float sc = a.row_scale ? a.row_scale[er[j]] : 1.0f;
-          a.post_c[pbase + pos[j]] = pack_coarse(local << a.coarse_shift, sc > 0.f ? vv[j] / sc : vv[j]);
+          const float wv_ = sc > 0.f ? vv[j] / sc : vv[j];
+          a.post_c[pbase + pos[j]] = a.coarse_wide ? pack_coarse_wide(local, wv_) : pack_coarse(local << a.coarse_shift, wv_);
         } else {
           Posting p;
           p.slot = local;
@@ -1275,7 +1284,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // picks S so that they stay below 2^8 (no carry into the neighbour's byte).
   constexpr bool SLOT2 = BLOCK <= 512;
   constexpr uint32_t ABITS = ACC8 ? 8u : 16u;  // accumulator width
-  static_assert(!ACC8 || BLOCK <= 512, "8-bit accumulators: the 512-thread kernel only");
+  // WIDE (ACC8 in the 1024-thread kernel): 131072-row tiles, one workgroup per CU, postings slot << 15 | fp15 weight
+  // (pack_coarse_wide).  The sparse regime (C5: 13 postings per (65536-row tile, term)) is bound by the traffic of
+  // half-empty 128-B lines -- one for the segment descriptor, one for the postings -- and twice the rows per tile
+  // halve both per posting visit.
+  constexpr bool WIDE = ACC8 && BLOCK > 512;
   constexpr int CH = CHUNK;              // postings per chunk: LPC lanes x 2 postings (8 B per lane)
   constexpr int LPC = CH / 2;            // lanes per chunk
   constexpr int GPW = kWave / LPC;       // chunks per wave step
@@ -1285,7 +1298,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // folds the array bases into the instructions' offset fields; through a dynamic `extern __shared__` base every LDS
   // access of the hot loop paid a VALU add of the (link-time) base.
   constexpr int kLongLen = kLongLenW;  // (128 / 512 for the prefetched sweeps measured slower: 710 / 884 vs 614 ms, C3 with Zipf(1))
-  constexpr int CBMAX = BLOCK <= 512 && !ACC8 ? 32768 : 65536;
+  constexpr int CBMAX = WIDE ? 131072 : (BLOCK <= 512 && !ACC8 ? 32768 : 65536);
   constexpr int APW = 32 / (int)ABITS;  // accumulators per LDS word
   __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / APW + kWave];  // two u16 / four u8 accumulators per word (+ slack)
   __shared__ uint2 items[NW * WIN];        // [NW][WIN] {byte offset of the chunk's first posting, weight bits}
@@ -1474,23 +1487,25 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     };
     // one coarse posting: 16-bit add into the candidate's half of its word; the returning atomic gives the old WORD
     // (the half is extracted later, so that the round's atomics are all in flight before the first wait)
-    auto slot_of = [&](const uint32_t pcw) { return SLOT2 && !ACC8 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu; };
+    auto slot_of = [&](const uint32_t pcw) { return WIDE ? pcw >> 15 : (SLOT2 && !ACC8 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu); };
     // the product of one posting, rounded up: floor(x) + 1 is never below x and >= 1, so that a touch always shows
     // SIGNED (weights of either sign, theta > 0): only the positive products count and a negative one adds a single
     // unit, so a sum is an upper bound of S * score that still grows with every touch -- sound for a filter (a pair
     // with score >= theta has at least that much positive mass); the exact pass applies the signs
     auto prod = [&](const uint32_t pcw, const float wqs) {
-      const float x = __builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(pcw >> 16))), 1.0f);
+      const float x = __builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(WIDE ? pcw & 0x7fffu : pcw >> 16))), 1.0f);
       return SIGNED ? (uint32_t)max((int)x, 1) : (uint32_t)x;
     };
     // ds_add_rtn_u32 on the word that holds the candidate's half; halves cannot carry (bounded scores)
     auto add16 = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
+      if (WIDE) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + ((pcw >> 15) & 0x1fffcu)), p << ((pcw >> 12) & 24u));
       if (SLOT2) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw & 0xfffcu)), p << ((pcw << 3) & 31u));
       const uint32_t slot = pcw & 0xffffu;
       return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));
     };
     auto half_of = [&](const uint32_t old_word, const uint32_t pcw) {
       // SLOT2: the low bits of the byte offset select the field; v_bfe_u32 takes the offset modulo 32
+      if (WIDE) return __builtin_amdgcn_ubfe(old_word, (pcw >> 12) & 24u, 8u);
       return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, ABITS) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
     };
     auto visit = [&](const uint32_t pcw, const float wqs) {
@@ -1693,7 +1708,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // unconditional: an idle lane (zero word) clears slot 0, which is zero at the end of a query either way
-        if (SLOT2 && ACC8) {
+        if (WIDE) {
+          smem_raw[w0.pc[u].x >> 15] = 0;  // ds_write_b8
+          smem_raw[w0.pc[u].y >> 15] = 0;
+        } else if (SLOT2 && ACC8) {
           smem_raw[w0.pc[u].x & 0xffffu] = 0;  // ds_write_b8
           smem_raw[w0.pc[u].y & 0xffffu] = 0;
         } else if (SLOT2) {
