@@ -1146,6 +1146,16 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       h->st.candidate_pairs = std::max(h->st.candidate_pairs, h->st.head_pairs);
     }
     h->st.result_pairs = (int64_t)c[kCtrResults];
+    if (cxv.acc8 && (int64_t)c[kCtrResults] > std::max<int64_t>(64 * nq, 4000000)) {
+      // the 8-bit filter turned out unselective on this data (skewed terms: chance pairs share dozens of them, and every
+      // shared term adds its unit of round-up): correct, but the survivors would swamp the exact pass.  Back to 16-bit
+      // accumulators, for good, and run the call again.
+      h->cx.cb = h->sharded ? 32768 : 65536;
+      h->cx.n_tiles = 0;
+      h->dbgcfg.no_acc8 = true;
+      APSS_TRY(build_index(h, 0));
+      return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_slot_first, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
+    }
     if (c[kCtrResults] > a.res_cap) {
       // the result list overflowed: grow to what the run asked for and repeat the (idempotent) probe
       const size_t need = (size_t)c[kCtrResults] + (size_t)c[kCtrResults] / 8 + 1024;
@@ -1206,8 +1216,15 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
         r.out_s = h->fin_s.p;
         r.out_count = h->counters.p;
         HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-        hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(n_cand * kGroup, 256)), dim3(256), 0, h->stream, r);
-        HIPCHK(h, hipGetLastError());
+        // (a launch may not have 2^32 threads or more: 16 lanes per pair -> at most 2^27 pairs per launch)
+        for (int64_t p0 = 0; p0 < n_cand; p0 += (1LL << 27)) {
+          RescoreArgs rr = r;
+          rr.n_pairs = std::min<int64_t>(1LL << 27, n_cand - p0);
+          rr.q_row = cand_q + p0;
+          rr.c_slot = cand_c + p0;
+          hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(rr.n_pairs * kGroup, 256)), dim3(256), 0, h->stream, rr);
+          HIPCHK(h, hipGetLastError());
+        }
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
         unsigned long long nfin = 0;
         HIPCHK(h, hipMemcpyAsync(&nfin, h->counters.p, sizeof(nfin), hipMemcpyDeviceToHost, h->stream));
@@ -1676,8 +1693,15 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
   a.out = d_out_partial;
   a.nq = h->last_nq;
   a.n_rows = h->n_rows;
-  hipLaunchKernelGGL(k_partial_scores, dim3((unsigned)ceil_div(n_pairs * kGroup, 256)), dim3(256), 0, h->stream, a);
-  HIPCHK(h, hipGetLastError());
+  for (int64_t p0 = 0; p0 < n_pairs; p0 += (1LL << 27)) {  // (a launch may not have 2^32 threads or more)
+    PartialArgs aa = a;
+    aa.n_pairs = std::min<int64_t>(1LL << 27, n_pairs - p0);
+    aa.q_row = d_q_row + p0;
+    aa.c_slot = d_c_slot + p0;
+    aa.out = d_out_partial + p0;
+    hipLaunchKernelGGL(k_partial_scores, dim3((unsigned)ceil_div(aa.n_pairs * kGroup, 256)), dim3(256), 0, h->stream, aa);
+    HIPCHK(h, hipGetLastError());
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return APSS_OK;
 }
