@@ -48,6 +48,7 @@ struct DebugCfg {
   bool no_tail = false;        // no_tail        every insert extends the tile index at once (no tail of waiting rows)
   bool no_acc8 = false;        // no_acc8        term shards keep 16-bit accumulators over 32768-row tiles
   int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
+  bool bank_order = false;     // bank_order     experiment: bank-aware posting order inside short segments (k_seg_bank_order)
 };
 
 DebugCfg parse_debug_env() {
@@ -78,6 +79,7 @@ DebugCfg parse_debug_env() {
     else if (key == "no_tail") d.no_tail = val != 0;
     else if (key == "no_acc8") d.no_acc8 = val != 0;
     else if (key == "seg_align") d.seg_align = val;
+    else if (key == "bank_order") d.bank_order = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -408,6 +410,9 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.post_c = ix.post_c.p;
   if (lds_build) hipLaunchKernelGGL(k_tile_scatter_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
   else hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
+  if (ix.coarse && ix.cb <= 32768 && h->dbgcfg.bank_order)
+    hipLaunchKernelGGL(k_seg_bank_order, dim3((unsigned)ceil_div((n_tiles - tile0) * stride * kWave, 256)), dim3(256), 0, h->stream,
+                       (const uint2 *)ix.seg.p, stride, (const int64_t *)ix.base.p, ix.post_c.p, tile0, n_tiles, h->cfg.dim);
   if (scaled)
     hipLaunchKernelGGL(k_tile_min_sub, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream,
                        (const float *)h->sub.p, h->idx_rows, (int32_t)cb, tmin.p, tile0);

@@ -426,6 +426,38 @@ __global__ __launch_bounds__(1024) void k_tile_scatter_lds(BuildArgs a, int64_t 
   }
 }
 
+// Bank-aware posting order inside a segment (coarse rendering, 16-bit accumulators, segments of <= 64 postings).  In the
+// probe, lane j of a chunk's 8 lanes adds postings 2j and 2j + 1 of the chunk, and one atomic instruction covers the same
+// position of 8 chunks (8 different segments).  Postings are ordered so that position 2j, 2j + 1 of a chunk hold candidates of
+// LDS bank class j (bank = (slot / 2) % 64, class = bank / 8): the 8 lanes of an instruction that share j then spread over 8
+// banks of their own instead of all 64 lanes over all 64 banks (expected deepest bank queue 2.3 instead of 3.5).
+// One wave per (tile, term) segment, one lane per posting; key = (rank in class / 2, class, rank in class % 2), position =
+// number of smaller keys.
+__global__ void k_seg_bank_order(const uint2 *tile_seg, int64_t seg_stride, const int64_t *tile_post_base, uint32_t *post_c,
+                                 int64_t tile0, int64_t n_tiles, int32_t dim) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int lane = threadIdx.x % kWave;
+  if (wave >= (n_tiles - tile0) * (int64_t)dim) return;
+  const int64_t tile = tile0 + wave / dim;
+  const int32_t term = (int32_t)(wave % dim);
+  const uint2 sg = tile_seg[tile * seg_stride + term];
+  if (sg.y < 3u || sg.y > (uint32_t)kWave) return;
+  uint32_t *p = post_c + tile_post_base[tile] + sg.x;
+  const bool live = (uint32_t)lane < sg.y;
+  const uint32_t w = live ? p[lane] : 0u;
+  const uint32_t cls = ((w & 0xffffu) >> 4) & 7u;  // slot field = slot * 2: bank = (field >> 2) & 63, class = bank >> 3
+  uint32_t rank = 0;
+#pragma unroll
+  for (uint32_t c = 0; c < 8; ++c) {
+    const unsigned long long m = __ballot(live && cls == c);
+    if (cls == c) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  }
+  const uint32_t key = live ? ((rank >> 1) << 4 | cls << 1 | (rank & 1u)) : 0xffffffffu;
+  uint32_t pos = 0;
+  for (int j = 0; j < kWave; ++j) pos += (uint32_t)__shfl((int)key, j) < key ? 1u : 0u;
+  if (live) p[pos] = w;  // every posting was read into a register before the first is written back (one wave, in order)
+}
+
 // per-tile minimum of the positive shard sub-norms (threshold scale of a tile in shard mode)
 __global__ void k_tile_min_sub(const float *sub, int64_t n_rows, int32_t cb, float *tile_min, int64_t tile0) {
   const int64_t tile = tile0 + blockIdx.x;
