@@ -707,6 +707,7 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
   X(512, 3, false, 16, false, false, false, true)    \
   X(512, 2, false, 16, false, false, false, true)    \
   X(512, 5, true, 16, false, false, true, false)     \
+  X(512, 5, true, 16, true, false, true, false)      \
   X(512, 4, false, 8, false, false, false, false)    \
   X(512, 5, false, 16, true, false, false, false)    \
   X(512, 5, false, 16, false, true, false, false)    \
@@ -904,7 +905,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const double cx_theta_used = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
   const bool coarse_path = h->use_coarse && (mode == 0 || cx_signed) && (cx_selective || a8_scale > 0) && cx_fp16_ok && !forced_general && nq < (1LL << 30) &&
                            !(shard_rule && h->cx.cb > 32768 && !(a8_scale > 0)) &&
-                           (q_max_nnz <= 512 || !shard_rule) &&
+                           (q_max_nnz <= 512 || !h->sharded) &&  // (long queries under the shard rule: the dense-head instantiation only)
                            !dbg.exact_accum && cx_scale > 0 && cx_theta < 65000.0 && (shard_rule || cx_theta - 2 >= 1.0) &&
                            std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
   // rows waiting in the tail are scored pair by pair after the join over the index; that needs the two-pass path's final

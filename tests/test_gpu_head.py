@@ -172,3 +172,17 @@ def test_unnormalised_rows_and_fallback(engine, oracle):
         want = to_map(*w.index_data(np.arange(50), rp[:51], idx[:rp[50]], val3[:rp[50]], query_only=True))
         assert_same_pairs(q, want, theta)
         assert ix.stats()["head_terms"] == 0
+
+
+def test_maildir_tfidf_with_a_forced_head_block(engine):
+    """BASELINE config 1 -- TF-IDF vectors of the reference's own mail corpus (HashingTF 2^20; real, Zipfian term
+    distribution; rows of up to 2,247 terms) -- through the dense-head path: the frequent terms in the bf16 block, the tail
+    under the shard rule with queries cut into parts of 512 terms.  Same pairs as the committed fixture (oracle output)"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maildir_small_tfidf.npz"))
+    dim, theta = int(z["dim"]), float(z["theta"])
+    want = to_map(z["out_q"], z["out_c"], z["out_sim"])
+    for kh in (64, 256):
+        got, st = _join(engine, dim, theta, z["rowptr"], z["indices"], z["values"], head_terms=kh)
+        assert st["head_terms"] == kh and st["head_pairs"] > 0
+        assert_same_pairs(got, want, theta)
