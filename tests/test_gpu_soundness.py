@@ -178,3 +178,48 @@ def test_signed_weights_with_near_cancelling_products(engine, oracle, seed):
     want, got, st = _check(engine, oracle, dim, theta, rows, tile_rows=int(rng.choice([64, 512])))
     assert len(want) > 100
     assert st["filter_survivors"] > st["result_pairs"]  # the upper bound lets cancelling pairs through; the exact pass drops them
+
+
+def _bf16_round_down_loss(x):
+    """relative amount by which round-to-nearest bf16 lowers x (negative: it raises it)"""
+    import struct
+    u = struct.unpack("<I", struct.pack("<f", np.float32(x)))[0]
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    y = struct.unpack("<f", struct.pack("<I", r))[0]
+    return (float(np.float32(x)) - y) / float(np.float32(x))
+
+
+def test_dense_head_filter_at_the_worst_case_of_bf16_rounding(engine, oracle):
+    """the dense-head filter's threshold is theta - 0.0080 max|q||c|: bf16 round-to-nearest may lower each factor of a
+    product by up to 2^-8.  Pairs built to sit right there: rows whose head part is k equal entries with 1/sqrt(k) just
+    below a bf16 rounding midpoint (every entry of W rounds DOWN by nearly 2^-8), scores a hair above theta; all found"""
+    # k whose 1/sqrt(k) loses the most in bf16
+    k = max(range(8, 65), key=lambda kk: _bf16_round_down_loss(1.0 / np.sqrt(kk)))
+    loss = _bf16_round_down_loss(1.0 / np.sqrt(k))
+    assert loss > 0.0030  # close to the 2^-8 = 0.0039 worst case
+    dim, theta = 400, 0.8
+    rows = []
+    head_terms = np.arange(k)
+    rng = np.random.default_rng(8)
+    # queries: unit rows, all mass on the k head terms (equal entries); candidates: the same direction, norm theta (1 + 3e-5)
+    for _ in range(40):
+        rows.append((head_terms, np.full(k, 1.0 / np.sqrt(k))))
+    for _ in range(40):
+        rows.append((head_terms, np.full(k, theta * (1 + 3e-5) / np.sqrt(k))))
+    # filler: rows over the other terms, so that terms 0 .. k-1 are the most frequent ones and nothing else pairs up
+    for _ in range(200):
+        t = np.sort(rng.choice(np.arange(64, dim), size=12, replace=False))
+        v = np.abs(rng.standard_normal(12)) + 0.1
+        rows.append((t, v / np.sqrt((v * v).sum())))
+    rp, idx, val = _csr(rows)
+    n = len(rows)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    near = [kv for kv in want.items() if abs(kv[1] - theta * (1 + 3e-5)) < 1e-6]
+    assert len(near) == 2 * 40 * 40  # every (unit row, short row) pair, both directions, score = theta (1 + 3e-5)
+    with engine.ApssIndex(dim, theta, head_terms=64) as ix:
+        got = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
+        st = ix.stats()
+    assert st["head_terms"] == 64 and st["head_survivors"] >= len(near)
+    missing = [kq for kq in want if kq not in got and abs(want[kq] - theta) > 1e-5]
+    assert not missing, (len(missing), missing[:3])
+    assert all(kq in want or abs(v - theta) <= 1e-5 for kq, v in got.items())
