@@ -1,0 +1,519 @@
+// k_probe_even: the FILTER pass of the two-pass join (k_probe_coarse's arithmetic and accumulators) restructured for
+// THIN rounds -- a term shard (BASELINE.json configs[3]: a dozen terms per query and shard) or a sparse regime -- where a
+// round carries a few hundred postings and its duration is a chain of latencies, not a throughput.
+//
+// What k_probe_coarse pays per round whatever the round holds: every wave stages its own share of the query's terms
+// (term k -> wave k % NW: descriptor loads, a wave-wide scan, strip writes: ~55 VALU instructions for two live lanes),
+// then adds, then -- after the first barrier -- an LDS read of the round's counters (survivors, overflow flag, long
+// list), the report loop, the clears and the second barrier: four dependent LDS round trips and two barriers, with two
+// workgroups per CU to hide them.  The T = 8 shard kernel measured 3,340 cycles per round (profiles/r02_summary.md).
+//
+// Here:
+//  * STAGING BY F WAVES.  The terms of round t go to waves (t + i) % NW, i < F (F = ceil(longest query / 64), lane =
+//    term), which scan them once, two rounds ahead, and deal the chunks out EVENLY over the A = NW - F waves that add in
+//    round t: chunk j -> adding wave j % A, strip slot j / A.  A wave that stages in a round adds nothing in it, so the
+//    staging is off the adding waves' path to the barrier; the others skip it altogether.
+//  * NOTHING IS READ AFTER THE FIRST BARRIER.  Everything a round needs to know about itself is a fact of its staging
+//    (chunks per wave, long segments, whether the window overflows -> whole-tile clear): it is read one round ahead, in
+//    the same LDS round trip as the next strip and the current adds.  A crossing is reported by the wave that sees it
+//    (ballot-compacted append to the global list), not through an LDS list that every wave re-reads after the barrier.
+//    So a round is: strip read + adds (one LDS round trip) -> tests, next loads -> barrier -> clears -> barrier.
+//
+// Pipeline (round v of a workgroup = one query against the tile's accumulators):
+//   round v - 4 : staging waves of v load the query's terms            (load_I)
+//   round v - 3 :                  load the (tile, term) descriptors   (load_P)
+//   round v - 2 :                  scan + write chunk descriptors into strips[v % 3], long segments into longs[v % 3]
+//   round v - 1 : every adding wave reads its strip and the round's facts, starts its posting loads
+//   round v     : adds + crossing tests (register window; chunks past the window straight from the strip), clear
+// The two workgroup barriers of round v - 2 separate the strip writes from their readers; the ring of three keeps the
+// strip of round v readable during round v while round v + 2 is being staged.
+//
+// A round whose chunks exceed the strips (A x SLOTS) or whose long segments exceed LONGCAP is flagged at staging and
+// swept by every wave straight from the index (one term per wave at a time): slow, unbounded, never wrong.
+// Queries of more than 64 x NW / 2 terms are not served (they stay with k_probe_coarse).
+#pragma once
+#include "apss_kernels.hpp"
+
+namespace apss {
+
+template <int BLOCK, int U, int LONGCAP, bool SHARD, bool SIGNED, bool ACC8, bool DIAG = false>
+__global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_even(const ProbeArgs a) {
+  constexpr int NW = BLOCK / kWave;
+  static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+  constexpr bool SLOT2 = BLOCK <= 512;
+  constexpr uint32_t ABITS = ACC8 ? 8u : 16u;
+  constexpr bool WIDE = ACC8 && BLOCK > 512;
+  constexpr int CH = 16, LPC = CH / 2, GPW = kWave / LPC, WIN = GPW * U;
+  constexpr int SLOTS = 2 * WIN < 48 ? 2 * WIN : 48;  // strip slots per wave and round (>= WIN)
+  static_assert(SLOTS >= WIN, "the register window reads the first WIN slots of a strip");
+  constexpr int kLongLen = kLongLenW;
+  constexpr int CBMAX = WIDE ? 131072 : (BLOCK <= 512 && !ACC8 ? 32768 : 65536);
+  constexpr int APW = 32 / (int)ABITS;
+  __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / APW + kWave];
+  __shared__ uint2 strips[3 * NW * SLOTS];  // [3][NW][SLOTS] {byte offset of the chunk's first posting, weight bits}
+  __shared__ uint2 longs[3 * LONGCAP];
+  __shared__ float long_w[3 * LONGCAP];
+  __shared__ uint4 facts[3];  // per ring slot: {chunks of the round, flagged for the direct sweep, long segments, -}
+  __shared__ unsigned long long stat[4];
+  unsigned char *const smem_raw = reinterpret_cast<unsigned char *>(acc);
+  uint32_t *const facts_w = reinterpret_cast<uint32_t *>(facts);
+
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
+  const int cb = a.cb;
+  const int F = a.flat_waves;   // waves that stage a round
+  // lanes per term in a staging wave (1, 2 or 4): a staging lane writes the chunks k = sub, sub + G, ... of its term, so a
+  // term of <= G chunks costs every lane ONE strip write (a wave issues an instruction every 4+ cycles whatever the number
+  // of live lanes: the staging wave's instruction count is the round's critical path)
+  const int LOGG = a.flat_group_log2, G = 1 << LOGG;
+  const uint32_t sub = (uint32_t)ln & (uint32_t)(G - 1);
+  const int A = NW - F;         // waves that add a round (those not staging in it)
+  const int CAP = A * SLOTS;    // chunks per round
+  const float rcpA = 1.0f / (float)A;
+  const int tile = a.tile0 + blockIdx.x / a.n_chunks;
+  const int chunk = blockIdx.x % a.n_chunks;
+  const int v0 = chunk * a.q_chunk;
+  const int v1 = min(a.nq, v0 + a.q_chunk);
+  const int nv = a.nq;
+  const int64_t tile_row0 = (int64_t)tile * cb;
+  const uint32_t lo = (uint32_t)(ln % LPC);
+  const float cxs = a.cx_scale;
+
+  const int64_t qbase = a.q_rowptr[v0], qend = a.q_rowptr[v1];
+  const int64_t pbase = a.tile_post_base[tile], pend = a.tile_post_base[tile + 1];
+  const __amdgpu_buffer_rsrc_t rs_qi =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_idx + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_qv =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_val + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_tp = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.tile_seg + (int64_t)tile * a.seg_stride), 0, (int)(a.seg_stride * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_po =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(a.post_c + pbase), 0, (int)((pend - pbase) * 4), 0x00020000);
+  constexpr uint32_t kOob = 0xfffffff0u;
+
+  for (int i = tid * 4; i < cb / APW + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < 12) facts_w[tid] = 0;
+  unsigned long long my_visits = 0;
+  uint32_t wave_cands = 0, my_cands = 0;
+
+  struct RowExt { int qb; int nnz; };  // as loaded: the low halves of the row's rowptr entries
+  struct TermW { uint32_t term; float w, qs; bool valid; };
+  struct Seg { uint32_t s, len; float w; };
+  struct WaveWork {
+    int mc;            // chunks of the round dealt to this wave
+    int rank;          // this wave's rank among the round's adding waves (< 0: it stages in that round)
+    uint32_t n_long;   // long segments of the round (swept by the whole workgroup)
+    bool direct;       // the round was flagged at staging: swept straight from the index
+    bool full_zero;    // the round ends with a whole-tile clear (long or direct sweeps, or a window that overflows)
+    apss_u32x2 pc[U];  // two coarse postings per lane and step
+    float wq[U];       // query weight x cx_scale of the step's chunk
+  };
+  // Every stage only ISSUES its loads; whatever is computed from a loaded value is computed by the NEXT stage, a round
+  // later (an operation on a value just loaded is a wait for the memory round trip, on the path to the barrier).  The
+  // per-row facts -- row extent, shard factor -- are loaded by the staging lanes themselves as vector loads, after the
+  // round's first adds: a scalar prefetched by every wave cost SGPRs the kernel does not have (the spill forced a wait
+  // for the scalar load at the top of every round), and a vector load at the top of the round would sit in the in-order
+  // wait for the round's postings.
+  const int32_t *const rowptr_lo = reinterpret_cast<const int32_t *>(a.q_rowptr);
+  const int qbase_lo = (int)(uint32_t)qbase;
+  auto load_R = [&](int v) {  // raw: the low halves of rowptr[v], rowptr[v + 1]
+    RowExt r;
+    const int vv = min(v, nv - 1);
+    r.qb = rowptr_lo[2 * vv];
+    r.nnz = rowptr_lo[2 * vv + 2];
+    return r;
+  };
+  // the staging waves of round t: (t + i) % NW, i < F; wave w is the i-th when (w - t) % NW == i
+  auto flat_index = [&](const int t) { return (wv - t) & (NW - 1); };
+  auto load_I = [&](const RowExt &r, const int fi, const int v) {
+    TermW t;
+    const int kterm = ((fi * kWave) >> LOGG) + (ln >> LOGG);
+    const int nnz = v < v1 ? r.nnz - r.qb : 0;
+    t.valid = kterm < nnz;
+    const uint32_t off = t.valid ? (uint32_t)(r.qb - qbase_lo + kterm) * 4u : kOob;  // (< 2^31: a workgroup's slice of the batch)
+    t.term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
+    t.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0));
+    t.qs = SHARD ? a.q_scale[min(v, nv - 1)] : 1.0f;  // shard rule: |q_g| / |q|, the query's half of the normalisation
+    return t;
+  };
+  auto load_P = [&](const TermW &t) {
+    Seg g;
+    const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, t.valid ? t.term * 8u : kOob, 0, 0);
+    g.s = sg.x;
+    g.len = sg.y;
+    // (rcp: 1 ulp; the coarse threshold's two units of slack cover the 2^-6 units it can add up to over a whole row)
+    g.w = SHARD ? (t.qs > 0.f ? t.w * __builtin_amdgcn_rcpf(t.qs) : 0.f) : t.w;
+    return g;
+  };
+  unsigned long long fs[4] = {0, 0, 0, 0};  // (DIAG stamps inside the staging)
+  // staging of one round by one of its F waves
+  auto flatten = [&](const Seg &g, const int ring) {
+    uint32_t len = g.len;
+    my_visits += sub == 0u ? len : 0u;
+    bool bad = false;
+    const float w = g.w;
+    if (len > (uint32_t)kLongLen) {
+      if (sub == 0u) {
+        const uint32_t k = atomicAdd(&facts_w[4 * ring + 2], 1u);
+        if (k < (uint32_t)LONGCAP) {
+          longs[ring * LONGCAP + k] = make_uint2(g.s, len);
+          long_w[ring * LONGCAP + k] = w;
+        } else {
+          bad = true;
+        }
+      }
+      len = 0;
+    }
+    const uint32_t nch = (len + CH - 1) / CH;
+    const uint32_t mine = sub == 0u ? nch : 0u;  // a term counts once, in the first lane of its group
+    if (DIAG) fs[0] = __builtin_readcyclecounter();
+    const uint32_t incl = wave_incl_scan(mine);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+    uint32_t base = 0;
+    if (F == 1) {
+      if (ln == 0) facts_w[4 * ring] = tot;
+    } else {
+      uint32_t b = 0;
+      if (ln == 0) b = atomicAdd(&facts_w[4 * ring], tot);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    }
+    if (DIAG) fs[1] = __builtin_readcyclecounter();
+    bad |= base + tot > (uint32_t)CAP;
+    if (__any(bad)) {
+      if (ln == 0) facts_w[4 * ring + 1] = 1u;  // the round is swept straight from the index; whatever was staged is ignored
+      return;
+    }
+    uint32_t j0 = base + incl - mine;
+    if (G > 1) j0 = (uint32_t)__shfl((int)j0, ln & ~(G - 1));  // the group's first lane holds the term's first chunk index
+    const uint32_t wbits = __float_as_uint(cxs * w);
+    uint2 *const st = strips + ring * (NW * SLOTS);
+    auto put = [&](const uint32_t k) {
+      if (k < nch) {
+        // chunk j of the round -> adding wave j % A, slot j / A ((j + 0.5) / A is at least 1 / 2A away from an integer:
+        // the float quotient truncates exactly for j < 2^16)
+        const uint32_t j = j0 + k;
+        const uint32_t sl = (uint32_t)(((float)j + 0.5f) * rcpA);
+        st[(j - sl * (uint32_t)A) * SLOTS + sl] = make_uint2((g.s + k * CH) * 4u, wbits);
+      }
+    };
+    // (segments of up to 2 G chunks without the loop; G = 1: up to 3)
+    if (DIAG) fs[2] = __builtin_readcyclecounter();
+    put(sub);
+    put(sub + (uint32_t)G);
+    if (G == 1) put(2u);
+    const uint32_t done = G == 1 ? 3u : 2u * (uint32_t)G;
+    if (__any(nch > done))
+      for (uint32_t k = done + sub; __any(k < nch); k += (uint32_t)G) put(k);
+    if (DIAG) fs[3] = __builtin_readcyclecounter();
+  };
+  // the next round of this wave, first half: its facts and its strip (LDS reads, issued ahead of the current round's adds so
+  // that one LDS round trip serves both)
+  struct StripRead { uint4 fc; uint2 it[U]; };
+  auto strip_read = [&](StripRead &sr, const int ring, const int rank) {
+    sr.fc = facts[ring];
+    const uint2 *const st = strips + (ring * NW + max(rank, 0)) * SLOTS;
+#pragma unroll
+    for (int u = 0; u < U; ++u) sr.it[u] = st[u * GPW + ln / LPC];
+  };
+  // second half: every LPC lanes take one chunk of the strip and start its posting load
+  auto strip_loads = [&](WaveWork &f, StripRead &sr, const int rank) {
+    const bool direct = sr.fc.y != 0u;
+    const int tot = direct ? 0 : (int)sr.fc.x;
+    // chunks j < tot with j % A == rank: ceil((tot - rank) / A)
+    const int mine = rank >= 0 && tot > rank ? (int)(((float)(tot - rank + A - 1) + 0.5f) * rcpA) : 0;
+    f.mc = __builtin_amdgcn_readfirstlane(mine);
+    f.rank = rank;
+    f.direct = __builtin_amdgcn_readfirstlane((int)direct) != 0;
+    f.n_long = direct ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)min(sr.fc.z, (uint32_t)LONGCAP));
+    f.full_zero = f.direct || f.n_long > 0u || __builtin_amdgcn_readfirstlane(tot) > A * WIN;
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(sr.it[u].x), "+v"(sr.it[u].y));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // a posting word of zero is no posting (segments are zero-padded to whole chunks; out-of-range reads return zero);
+      // a strip slot past the wave's last chunk holds a stale descriptor: its load is sent out of range
+      f.wq[u] = __uint_as_float(sr.it[u].y);
+      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, u * GPW + ln / LPC < f.mc ? sr.it[u].x + lo * 8u : kOob, 0, 0);
+    }
+  };
+
+  RowExt R4 = load_R(v0 + 4);   // extent of row v + 4 at the top of round v (staging waves of that round only)
+  TermW Ic;   // terms of round v + 3 (when this wave stages it)
+  Seg Pc;     // descriptors of round v + 2
+  WaveWork wfa, wfb;
+  {
+    const TermW I0 = load_I(load_R(v0), flat_index(v0), v0), I1 = load_I(load_R(v0 + 1), flat_index(v0 + 1), v0 + 1),
+                I2 = load_I(load_R(v0 + 2), flat_index(v0 + 2), v0 + 2);
+    Ic = load_I(load_R(v0 + 3), flat_index(v0 + 3), v0 + 3);
+    const Seg P0 = load_P(I0), P1 = load_P(I1);
+    Pc = load_P(I2);
+    __syncthreads();
+    if (flat_index(v0) < F) flatten(P0, 0);
+    if (flat_index(v0 + 1) < F) flatten(P1, 1);
+    __syncthreads();
+    StripRead sr;
+    strip_read(sr, 0, flat_index(v0 + 2) - F);
+    strip_loads(wfa, sr, flat_index(v0 + 2) - F);
+  }
+
+  // DIAG: cycle stamps of an adding wave's round, differenced at the end of the round (shares only)
+  unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto round = [&](WaveWork &w0, WaveWork &w2, const int v, const int r0) {
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tw = 0;
+    if (DIAG) {
+      ts[0] = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tw = __builtin_readcyclecounter();
+    }
+    const int r1 = r0 == 2 ? 0 : r0 + 1, r2 = r1 == 2 ? 0 : r1 + 1;
+    const int q = v;
+    constexpr int slack = 2;  // (k_probe_coarse: the soundness argument of the coarse threshold)
+    const int thr_c = (int)a.cx_theta - slack;
+    const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
+    RowExt R5 = R4;  // the extent of row v + 5, loaded by the waves that will stage that round, used a round later
+    const int f5 = flat_index(v + 5);
+
+    // a crossing, reported by the wave that sees it (uniform control flow: one global atomic per wave and call)
+    auto report = [&](const bool cross, const uint32_t slot, const uint32_t sum) {
+      bool ok = cross;
+      if (ok) ok = a.ext_id[tile_row0 + slot] != a.q_ext[q];
+      const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+      if (ok && o < a.res_cap) {
+        a.res_q[o] = q;
+        a.res_c[o] = (int32_t)(tile_row0 + slot);
+        a.res_s[o] = (float)sum / cxs;  // coarse score at the crossing, replaced by k_rescore
+      }
+    };
+    // the same from divergent control flow (sweeps): one atomic per lane
+    auto report_lane = [&](const uint32_t slot, const uint32_t sum) {
+      if (a.ext_id[tile_row0 + slot] != a.q_ext[q]) {
+        const uint64_t o = atomicAdd(&a.counters[kCtrResults], 1ull);
+        if (o < a.res_cap) {
+          a.res_q[o] = q;
+          a.res_c[o] = (int32_t)(tile_row0 + slot);
+          a.res_s[o] = (float)sum / cxs;
+        }
+      }
+    };
+    auto slot_of = [&](const uint32_t pcw) { return WIDE ? pcw >> 15 : (SLOT2 && !ACC8 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu); };
+    auto prod = [&](const uint32_t pcw, const float wqs) {
+      const float x = __builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(WIDE ? pcw & 0x7fffu : pcw >> 16))), 1.0f);
+      return SIGNED ? (uint32_t)max((int)x, 1) : (uint32_t)x;
+    };
+    auto add16 = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
+      if (WIDE) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + ((pcw >> 15) & 0x1fffcu)), p << ((pcw >> 12) & 24u));
+      if (SLOT2) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw & 0xfffcu)), p << ((pcw << 3) & 31u));
+      const uint32_t slot = pcw & 0xffffu;
+      return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));
+    };
+    auto half_of = [&](const uint32_t old_word, const uint32_t pcw) {
+      if (WIDE) return __builtin_amdgcn_ubfe(old_word, (pcw >> 12) & 24u, 8u);
+      return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, ABITS) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
+    };
+    auto visit = [&](const uint32_t pcw, const float wqs) {  // (sweeps: divergent control flow)
+      const uint32_t p = prod(pcw, wqs);
+      const uint32_t old16 = half_of(add16(pcw, p), pcw);
+      my_cands += old16 == 0u ? 1u : 0u;
+      if (thr1 - old16 < p) report_lane(slot_of(pcw), old16 + p);
+    };
+    constexpr int BATCH = 3;
+    // An idle lane (zero word) adds into ITS OWN spare word behind the accumulators (a select on the address) instead of
+    // being masked off: an exec mask around each atomic is a trip VALU -> scalar unit -> VALU (compare, s_and_saveexec,
+    // s_or) that cost ~64 cycles of the wave's serial issue per posting slot (profiles/microbench/issue_rate.hip).  Its
+    // "old value" is replaced by thr1 + 1 afterwards: never a first touch (not 0), never a crossing (thr1 - old wraps).
+    const uint32_t spare = (uint32_t)(CBMAX / APW) * 4u + (uint32_t)ln * 4u;
+    auto add_or_spare = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
+      const uint32_t addr = WIDE ? (pcw >> 15) & 0x1fffcu : (SLOT2 ? pcw & 0xfffcu : ((pcw & 0xffffu) >> 1) * 4u);
+      const uint32_t sh = WIDE ? (pcw >> 12) & 24u : (SLOT2 ? (pcw << 3) & 31u : (pcw & 1u) << 4);
+      return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw ? addr : spare)), p << sh);
+    };
+    auto issue_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int u = u0 + j;
+        if (u < U) {
+          p0[j] = prod(w0.pc[u].x, w0.wq[u]);
+          p1[j] = prod(w0.pc[u].y, w0.wq[u]);
+          o0[j] = add_or_spare(w0.pc[u].x, p0[j]);
+          o1[j] = add_or_spare(w0.pc[u].y, p1[j]);
+        }
+      }
+    };
+    auto check_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
+      // first touches and crossings are counted per lane (VALU only); one trip to the scalar unit per batch decides
+      // whether any lane crossed
+      uint32_t n_cross = 0;
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int u = u0 + j;
+        if (u < U) {
+          o0[j] = w0.pc[u].x ? half_of(o0[j], w0.pc[u].x) : thr1 + 1u;
+          o1[j] = w0.pc[u].y ? half_of(o1[j], w0.pc[u].y) : thr1 + 1u;
+          my_cands += (o0[j] == 0u ? 1u : 0u) + (o1[j] == 0u ? 1u : 0u);
+          n_cross += (thr1 - o0[j] < p0[j] ? 1u : 0u) + (thr1 - o1[j] < p1[j] ? 1u : 0u);
+        }
+      }
+      if (__any(n_cross != 0u)) {
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int u = u0 + j;
+          if (u < U) {
+            report(thr1 - o0[j] < p0[j], slot_of(w0.pc[u].x), o0[j] + p0[j]);
+            report(thr1 - o1[j] < p1[j], slot_of(w0.pc[u].y), o1[j] + p1[j]);
+          }
+        }
+      }
+    };
+    // a wave that stages round v + 2 adds nothing in round v (no chunk of round v was dealt to it): the staging is off
+    // the adding waves' path to the barrier
+    const int f4 = flat_index(v + 4), f3 = flat_index(v + 3), f2 = flat_index(v + 2);
+    const int rank1 = f3 - F;  // this wave's rank among the adding waves of round v + 1 (which stages round v + 3)
+    TermW In = Ic;
+    Seg Pn = Pc;
+    StripRead sr;
+    if (f2 < F) {
+      if (f5 < F) R5 = load_R(v + 5);
+      if (f4 < F) In = load_I(R4, f4, v + 4);
+      if (f3 < F) Pn = load_P(Ic);
+      strip_read(sr, r1, rank1);
+      flatten(Pc, r2);
+      strip_loads(w2, sr, rank1);
+    } else {
+      strip_read(sr, r1, rank1);
+      {
+        uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
+        issue_batch(0, p0, p1, o0, o1);
+        if (f5 < F) R5 = load_R(v + 5);
+        if (f4 < F) In = load_I(R4, f4, v + 4);
+        if (f3 < F) Pn = load_P(Ic);
+        if (DIAG) ts[1] = __builtin_readcyclecounter();
+        strip_loads(w2, sr, rank1);
+        check_batch(0, p0, p1, o0, o1);
+      }
+#pragma unroll
+      for (int u0 = BATCH; u0 < U; u0 += BATCH) {
+        uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
+        issue_batch(u0, p0, p1, o0, o1);
+        check_batch(u0, p0, p1, o0, o1);
+      }
+      if (w0.mc > WIN) {  // chunks past the register window: straight from this wave's strip
+        const uint2 *const st = strips + (r0 * NW + w0.rank) * SLOTS;
+        for (int c0 = WIN; c0 < w0.mc; c0 += GPW) {
+          const int c = c0 + ln / LPC;
+          const uint2 it = st[min(c, SLOTS - 1)];
+          const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, c < w0.mc ? it.x + lo * 8u : kOob, 0, 0);
+          if (two.x) visit(two.x, __uint_as_float(it.y));
+          if (two.y) visit(two.y, __uint_as_float(it.y));
+        }
+      }
+    }
+    Ic = In;
+    Pc = Pn;
+    if (w0.direct) {  // flagged at staging: every term straight from the index, one term per wave at a time
+      RowExt cur = load_R(v);
+      cur.nnz -= cur.qb;
+      cur.qb -= qbase_lo;
+      const float qsv = SHARD ? uniform_load(a.q_scale + v) : 1.0f;
+      const float iq = qsv > 0.f ? 1.0f / qsv : 0.f;
+      for (int k = wv; k < cur.nnz; k += NW) {
+        const uint32_t off = (uint32_t)(cur.qb + k) * 4u;
+        const uint32_t term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
+        const float wq_ = cxs * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0)) * iq;
+        const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, term * 8u, 0, 0);
+        for (uint32_t p = 2u * (uint32_t)ln; p < sg.y; p += 2u * kWave) {
+          const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sg.x + p) * 4u, 0, 0);
+          if (two.x) visit(two.x, wq_);
+          if (two.y && p + 1u < sg.y) visit(two.y, wq_);
+        }
+      }
+    }
+    for (uint32_t j = 0; j < w0.n_long; ++j) {
+      const uint2 sgm = longs[r0 * LONGCAP + j];
+      const float wq_ = cxs * long_w[r0 * LONGCAP + j];
+      uint32_t k = 2u * tid;
+      for (; k + 2u * BLOCK < sgm.y; k += 4u * BLOCK) {
+        const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+        const apss_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2u * BLOCK) * 4u, 0, 0);
+        visit(a0.x, wq_);
+        if (k + 1u < sgm.y) visit(a0.y, wq_);
+        visit(a1.x, wq_);
+        if (k + 2u * BLOCK + 1u < sgm.y) visit(a1.y, wq_);
+      }
+      for (; k < sgm.y; k += 2u * BLOCK) {
+        const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+        visit(a0.x, wq_);
+        if (k + 1u < sgm.y) visit(a0.y, wq_);
+      }
+    }
+    if (DIAG) ts[2] = __builtin_readcyclecounter();
+    __syncthreads();  // every add of the round has landed
+    if (DIAG) ts[3] = __builtin_readcyclecounter();
+
+    if (w0.full_zero) {
+      for (int i = tid * 4; i < cb / APW; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+    } else if (f2 >= F) {
+      unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // unconditional: an idle lane (zero word) clears slot 0, which is zero at the end of a query either way
+        if (WIDE) {
+          smem_raw[w0.pc[u].x >> 15] = 0;
+          smem_raw[w0.pc[u].y >> 15] = 0;
+        } else if (SLOT2 && ACC8) {
+          smem_raw[w0.pc[u].x & 0xffffu] = 0;
+          smem_raw[w0.pc[u].y & 0xffffu] = 0;
+        } else if (SLOT2) {
+          *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].x & 0xffffu)) = 0;
+          *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].y & 0xffffu)) = 0;
+        } else {
+          acc16w[w0.pc[u].x & 0xffffu] = 0;
+          acc16w[w0.pc[u].y & 0xffffu] = 0;
+        }
+      }
+    }
+    if (tid == 0) facts[r0] = make_uint4(0u, 0u, 0u, 0u);  // (read one round ago; staged again in the next round)
+    if (DIAG) ts[4] = __builtin_readcyclecounter();
+    __syncthreads();  // cleared: the next query starts from zero
+    if (DIAG) {
+      ts[5] = __builtin_readcyclecounter();
+      if (f2 >= F) {
+        for (int k = 1; k < 5; ++k) tsum[k] += ts[k + 1] - ts[k];
+        tsum[0] += ts[1] - tw;
+        tsum[5] += tw - ts[0];
+      } else {
+        tsum[6] += ts[2] - tw;
+        tsum[7] += 1;
+        tsum[8] += fs[0] - tw;     // loads of later rounds, strip read, chunk counts
+        tsum[9] += fs[1] - fs[0];  // scan + base
+        tsum[10] += fs[2] - fs[1]; // group broadcast
+        tsum[11] += fs[3] - fs[2]; // strip writes
+        tsum[12] += ts[2] - fs[3]; // next loads
+      }
+    }
+
+    R4 = R5;
+  };
+  int r0 = 0;
+  for (int v = v0; v < v1; v += 2) {
+    round(wfa, wfb, v, r0);
+    r0 = r0 == 2 ? 0 : r0 + 1;
+    if (v + 1 >= v1) break;
+    round(wfb, wfa, v + 1, r0);
+    r0 = r0 == 2 ? 0 : r0 + 1;
+  }
+  if (DIAG && ln == 0 && a.dbg)
+    for (int k = 0; k < 16; ++k) atomicAdd(&a.dbg[k], tsum[k]);
+  __syncthreads();
+  if (tid < 3) stat[tid] = 0;
+  __syncthreads();
+  atomicAdd(&stat[0], my_visits);
+  atomicAdd(&stat[1], (unsigned long long)my_cands + (ln == 0 ? wave_cands : 0u));
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&a.counters[kCtrVisits], stat[0]);
+    atomicAdd(&a.counters[kCtrCands], stat[1]);
+  }
+}
+
+}  // namespace apss

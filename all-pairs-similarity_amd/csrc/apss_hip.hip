@@ -17,6 +17,7 @@
 #include "../../include/apss.h"
 #include "apss_kernels.hpp"
 #include "apss_head.hpp"
+#include "apss_even.hpp"
 
 using namespace apss;
 
@@ -47,6 +48,8 @@ struct DebugCfg {
   int tiles_per_launch = 0;    // tiles_per_launch=N
   bool no_tail = false;        // no_tail        every insert extends the tile index at once (no tail of waiting rows)
   bool no_acc8 = false;        // no_acc8        term shards keep 16-bit accumulators over 32768-row tiles
+  int pad_lds = 0;             // pad_lds=N      N bytes of dynamic LDS on the filter launch (occupancy experiments)
+  bool no_even = false;        // no_even        the filter stages every round on all waves (k_probe_coarse), never on F of them (k_probe_even)
   int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
   bool bank_order = false;     // bank_order     experiment: bank-aware posting order inside short segments (k_seg_bank_order)
 };
@@ -78,6 +81,8 @@ DebugCfg parse_debug_env() {
     else if (key == "tiles_per_launch") d.tiles_per_launch = val;
     else if (key == "no_tail") d.no_tail = val != 0;
     else if (key == "no_acc8") d.no_acc8 = val != 0;
+    else if (key == "no_even") d.no_even = val != 0;
+    else if (key == "pad_lds") d.pad_lds = (int)val;
     else if (key == "seg_align") d.seg_align = val;
     else if (key == "bank_order") d.bank_order = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
@@ -728,9 +733,43 @@ struct CxVariant {
   bool vrows, sgn;
   bool longpf;  // prefetched long-segment sweeps: the sparse half of a handle with a dense-head block
   bool acc8;    // 8-bit accumulators over 65536-row tiles: thin rounds of a term shard
+  bool even;    // k_probe_even: a round is staged by ceil(longest query / 64) waves and its chunks dealt out evenly
 };
 
+// k_probe_even's instantiations: (threads, window steps, shard rule, signed weights, 8-bit accumulators)
+#define APSS_EVEN_VARIANTS(X)          \
+  X(512, 5, false, false, false)       \
+  X(512, 4, false, false, false)       \
+  X(512, 3, false, false, false)       \
+  X(512, 2, false, false, false)       \
+  X(512, 5, true, false, false)        \
+  X(512, 4, true, false, false)        \
+  X(512, 3, true, false, false)        \
+  X(512, 2, true, false, false)        \
+  X(512, 5, true, false, true)         \
+  X(512, 4, true, false, true)         \
+  X(512, 3, true, false, true)         \
+  X(512, 2, true, false, true)         \
+  X(512, 5, false, false, true)        \
+  X(512, 4, false, false, true)        \
+  X(512, 3, false, false, true)        \
+  X(512, 2, false, false, true)        \
+  X(512, 5, false, true, false)        \
+  X(1024, 5, false, false, false)      \
+  X(1024, 3, false, false, false)      \
+  X(1024, 5, false, true, false)       \
+  X(1024, 3, false, true, false)       \
+  X(1024, 5, false, false, true)       \
+  X(1024, 3, false, false, true)
+
 bool cx_variant_exists(const CxVariant &v) {
+  if (v.even) {
+#define X(B, U, SH, SG, A8) \
+    if (v.block == B && v.u == U && v.shard == SH && v.sgn == SG && v.acc8 == A8) return v.chunk == 16 && !v.vrows && !v.longpf;
+    APSS_EVEN_VARIANTS(X)
+#undef X
+    return false;
+  }
 #define X(B, U, SH, CH, VR, SG, LP, A8)                                                                                 \
   if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG && v.longpf == LP &&   \
       v.acc8 == A8)                                                                                                     \
@@ -742,6 +781,18 @@ bool cx_variant_exists(const CxVariant &v) {
 
 int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
   const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
+  if (v.even) {
+#define X(B, U, SH, SG, A8)                                                                                                \
+    if (v.block == B && v.u == U && v.shard == SH && v.sgn == SG && v.acc8 == A8) {                                        \
+      hipLaunchKernelGGL((k_probe_even<B, U, (B <= 512 ? 128 : 256), SH, SG, A8>), grid, dim3(B),                          \
+                         (size_t)h->dbgcfg.pad_lds, h->stream, a);                                                                                 \
+      HIPCHK(h, hipGetLastError());                                                                                        \
+      return APSS_OK;                                                                                                      \
+    }
+    APSS_EVEN_VARIANTS(X)
+#undef X
+    return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
+  }
 #define X(B, U, SH, CH, VR, SG, LP, A8)                                                                                    \
   if (v.block == B && v.u == U && v.shard == SH && v.chunk == CH && v.vrows == VR && v.sgn == SG && v.longpf == LP &&      \
       v.acc8 == A8) {                                                                                                      \
@@ -1009,6 +1060,29 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       cxv.longpf = true;
     }
     cxv.u = u;
+    // k_probe_even (apss_even.hpp): the round staged by F waves, its chunks dealt out evenly -- a wave's window then holds a
+    // 1/NW share of the ROUND's chunks (mean + 3 sigma over rounds), not the chunks of the wave's own terms
+    // staging lanes per term: as many as keep the staging waves at <= a quarter of the workgroup
+    int flat_group_log2 = 2;
+    while (flat_group_log2 > 0 && ceil_div(q_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
+    const int64_t flat_waves = std::max<int64_t>(1, ceil_div(q_max_nnz, kWave >> flat_group_log2));
+    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 2) {
+      CxVariant ev = cxv;
+      ev.even = true;
+      const double add_waves = nw - (double)flat_waves;               // a wave that stages a round adds nothing in it
+      const double cpt = std::max(1.0, seg / 16.0 + 0.5);           // chunks per term
+      const double round_chunks = q_terms * cpt + 3.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
+      int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
+      const bool fits = ue <= 5;  // (a window that overflows most rounds pays a whole-tile clear each time)
+      ue = cxv.block == 1024 ? (ue <= 3 ? 3 : 5) : std::max(2, std::min(5, ue));
+      if (cxv.sgn) ue = 5;
+      ev.u = ue;
+      if (fits && cx_variant_exists(ev)) {
+        cxv = ev;
+        a.flat_waves = (int32_t)flat_waves;
+        a.flat_group_log2 = flat_group_log2;
+      }
+    }
     if (!cx_variant_exists(cxv)) return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
   }
   const int vrow_part = 512;
@@ -1087,7 +1161,23 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     for (int64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_launch, ++n_launches) {
       a.tile0 = (int32_t)t0;
       a.n_tiles = (int32_t)std::min<int64_t>(tiles_per_launch, total_tiles - t0);
-      if (coarse_path) {
+      if (coarse_path && dbg.diag && cxv.even && cxv.block == 512 && cxv.u == 2 && cxv.shard && cxv.acc8 && !cxv.sgn) {
+        // diagnostic build of the thin-round instantiation: cycle stamps of a round's segments (shares only)
+        APSS_TRY(ensure(h, h->dbg, 16));
+        HIPCHK(h, hipMemsetAsync(h->dbg.p, 0, 16 * sizeof(unsigned long long), h->stream));
+        a.dbg = h->dbg.p;
+        hipLaunchKernelGGL((k_probe_even<512, 2, 128, true, false, true, true>), dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)),
+                           dim3(512), (size_t)dbg.pad_lds, h->stream, a);
+        HIPCHK(h, hipGetLastError());
+        unsigned long long d[16];
+        HIPCHK(h, hipMemcpyAsync(d, h->dbg.p, sizeof(d), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const double ns = (double)std::max<unsigned long long>(1, d[7]), n = (double)a.n_tiles * a.nq * 8.0 - ns;
+        fprintf(stderr, "[apss diag even] per adding wave-round (cycle-counter ticks): wait for the postings %.0f | prods + issue of adds %.0f | "
+                        "LDS return, next loads, tests %.0f | barrier 1 %.0f | clears %.0f | barrier 2 %.0f || staging wave, after its loads arrived, to barrier 1: %.0f "
+                        "= loads + strip read %.0f + scan, base %.0f + broadcast %.0f + strip writes %.0f + next loads %.0f\n",
+                d[5] / n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[6] / ns, d[8] / ns, d[9] / ns, d[10] / ns, d[11] / ns, d[12] / ns);
+      } else if (coarse_path) {
         APSS_TRY(launch_cx(h, cxv, a));
       } else if (wave_path && dbg.diag) {
         // diagnostic build: in-kernel cycle stamps per round segment (shares only; never a benchmark number)

@@ -33,6 +33,15 @@ struct alignas(8) Posting {
   float w;
 };
 
+// Wave-uniform load of a read-only kernel input through the SCALAR cache (s_load): the constant address space tells the
+// compiler the location is invariant for the kernel's lifetime.  As an ordinary global load a per-row fact (a row extent,
+// a shard factor, an external id) is a VECTOR memory instruction on the in-order vmcnt counter: issued at the top of a
+// round it sits behind the round's posting loads in the wait before the first add -- a memory round trip per round.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T *p) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
 enum Counter { kCtrResults = 0, kCtrVisits = 1, kCtrCands = 2, kCtrFlags = 3, kCtrCount = 4 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -503,6 +512,8 @@ struct ProbeArgs {
   int32_t nq;
   int32_t q_chunk;          // queries per workgroup
   int32_t n_chunks;
+  int32_t flat_waves;       // k_probe_even: waves that stage a round = ceil(longest query row / (64 / lanes per term))
+  int32_t flat_group_log2;  // k_probe_even: log2 of the staging lanes per term (0, 1 or 2)
   int64_t q_slot_base;      // slot of query row 0 when the batch is stored in the index, else -1
   float theta;
   float fx_scale;     // fixed-point accumulators: 1.0 is this many units (2^30 or 2^28), k_probe_wave
@@ -1401,8 +1412,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       r.q = a.vrow_q[vv];
       r.last = a.vrow_q[vv + 1] != r.q;
     } else {
-      b = a.q_rowptr[vv];
-      e = a.q_rowptr[vv + 1];
+      b = uniform_load(a.q_rowptr + vv);
+      e = uniform_load(a.q_rowptr + vv + 1);
       r.q = vv;
       r.last = true;
     }
@@ -1410,7 +1421,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     r.nnz = v < v1 ? (int)(e - b) : 0;
     r.inv_qs = 1.0f;
     if (SHARD) {
-      const float qsv = a.q_scale[r.q];
+      const float qsv = uniform_load(a.q_scale + r.q);
       r.inv_qs = qsv > 0.f ? 1.0f / qsv : 0.f;
     }
     return r;
@@ -1509,7 +1520,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     const int thr_c = (int)a.cx_theta - slack;
     const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
 
-    const RowExt R4 = load_R(v + 4);
+    const RowExt R4 = load_R(v + 4);  // (scalar loads: uniform_load)
 
     auto crossed = [&](const uint32_t slot, const uint32_t p, const uint32_t old16) {
       if (thr1 - old16 < p) {
@@ -1550,34 +1561,43 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     // latency, few enough live registers to keep two workgroups on the CU.  The staging of round v + 1 (its own LDS
     // round trip and its posting loads) runs between the first batch's adds and their tests.
     constexpr int BATCH = 3;
+    // An idle lane (zero word) adds into ITS OWN spare word behind the accumulators (a select on the address) instead of
+    // being masked off: an exec mask around each atomic is a trip VALU -> scalar unit -> VALU (compare, s_and_saveexec,
+    // s_or) that cost ~64 cycles of the wave's serial issue per posting slot (profiles/microbench/issue_rate.hip).  Its
+    // "old value" is replaced by thr1 + 1 afterwards: never a first touch (not 0), never a crossing (thr1 - old wraps).
+    const uint32_t spare = (uint32_t)(CBMAX / APW) * 4u + (uint32_t)ln * 4u;
+    auto add_or_spare = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
+      const uint32_t addr = WIDE ? (pcw >> 15) & 0x1fffcu : (SLOT2 ? pcw & 0xfffcu : ((pcw & 0xffffu) >> 1) * 4u);
+      const uint32_t sh = WIDE ? (pcw >> 12) & 24u : (SLOT2 ? (pcw << 3) & 31u : (pcw & 1u) << 4);
+      return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw ? addr : spare)), p << sh);
+    };
     auto issue_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
-      // an idle lane (zero word) skips only the atomic; its "old value" thr1 + 1 is never a first touch (not 0) and
-      // never a crossing (thr1 - old wraps to 2^32 - 1), whatever its p
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         const int u = u0 + j;
         if (u < U) {
           p0[j] = prod(w0.pc[u].x, w0.wq[u]);
           p1[j] = prod(w0.pc[u].y, w0.wq[u]);
-          o0[j] = o1[j] = thr1 + 1u;
-          if (w0.pc[u].x) o0[j] = add16(w0.pc[u].x, p0[j]);
-          if (w0.pc[u].y) o1[j] = add16(w0.pc[u].y, p1[j]);
+          o0[j] = add_or_spare(w0.pc[u].x, p0[j]);
+          o1[j] = add_or_spare(w0.pc[u].y, p1[j]);
         }
       }
     };
     auto check_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
-      bool any_cross = false;
+      // first touches and crossings are counted per lane (VALU only); one trip to the scalar unit per batch decides
+      // whether any lane crossed
+      uint32_t n_cross = 0;
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         const int u = u0 + j;
         if (u < U) {
-          o0[j] = half_of(o0[j], w0.pc[u].x);
-          o1[j] = half_of(o1[j], w0.pc[u].y);
-          wave_cands += (uint32_t)__popcll(__ballot(o0[j] == 0u)) + (uint32_t)__popcll(__ballot(o1[j] == 0u));
-          any_cross |= (thr1 - o0[j] < p0[j]) | (thr1 - o1[j] < p1[j]);
+          o0[j] = w0.pc[u].x ? half_of(o0[j], w0.pc[u].x) : thr1 + 1u;
+          o1[j] = w0.pc[u].y ? half_of(o1[j], w0.pc[u].y) : thr1 + 1u;
+          my_cands += (o0[j] == 0u ? 1u : 0u) + (o1[j] == 0u ? 1u : 0u);
+          n_cross += (thr1 - o0[j] < p0[j] ? 1u : 0u) + (thr1 - o1[j] < p1[j] ? 1u : 0u);
         }
       }
-      if (any_cross) {
+      if (n_cross) {
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
           const int u = u0 + j;

@@ -26,7 +26,7 @@ def test_speed_kernels_keep_two_workgroups_per_cu(tmp_path):
                 res[cur][key.split(" ")[0]] = int(m.group(1))
     checked = 0
     for name, r in res.items():
-        two_per_cu = ("k_probe_coarseILi512" in name) or ("k_probe_waveILi512ELi5" in name)
+        two_per_cu = ("k_probe_coarseILi512" in name) or ("k_probe_waveILi512ELi5" in name) or ("k_probe_evenILi512" in name)
         # the long-query instantiation (VROWS, the boolean after the chunk size) is allowed its 8 B/lane of scratch: it is
         # kept separate exactly so that the common kernel stays clear of the register edge
         vrows = re.search(r"k_probe_coarseILi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi\d+ELb1(ELb[01])+EEE", name) is not None
@@ -35,6 +35,7 @@ def test_speed_kernels_keep_two_workgroups_per_cu(tmp_path):
             continue
         if two_per_cu:
             assert r["VGPRs"] <= 128 and r["ScratchSize"] == 0 and r["Occupancy"] >= 4, (name, r)
+            assert 2 * r["LDS"] <= 160 * 1024, (name, r)  # two workgroups' static LDS in the CU's 160 KB
             checked += 1
         if "k_probe" in name:
             assert r["ScratchSize"] == 0, (name, r)
