@@ -36,7 +36,7 @@
 
 namespace apss {
 
-template <int BLOCK, int U, int LONGCAP, bool SHARD, bool SIGNED, bool ACC8, bool DIAG = false>
+template <int BLOCK, int U, int LONGCAP, bool SHARD, bool SIGNED, bool ACC8>
 __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_even(const ProbeArgs a) {
   constexpr int NW = BLOCK / kWave;
   static_assert(NW == 8 || NW == 16, "8 or 16 waves");
@@ -49,11 +49,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   constexpr int kLongLen = kLongLenW;
   constexpr int CBMAX = WIDE ? 131072 : (BLOCK <= 512 && !ACC8 ? 32768 : 65536);
   constexpr int APW = 32 / (int)ABITS;
-  __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / APW + kWave];
-  __shared__ uint2 strips[3 * NW * SLOTS];  // [3][NW][SLOTS] {byte offset of the chunk's first posting, weight bits}
+  __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / APW + kWave];  // (+ one spare word per lane: idle lanes add there)
+  __shared__ uint2 strips[3 * NW * SLOTS + kWave];  // [3][NW][SLOTS] {byte offset of the chunk's first posting, weight bits} (+ one spare entry per lane)
   __shared__ uint2 longs[3 * LONGCAP];
   __shared__ float long_w[3 * LONGCAP];
-  __shared__ uint4 facts[3];  // per ring slot: {chunks of the round, flagged for the direct sweep, long segments, -}
+  __shared__ uint2 facts[4];  // per ring slot: {chunks of the round, bit 0: flagged for the direct sweep, bits 1..: long segments}
   __shared__ unsigned long long stat[4];
   unsigned char *const smem_raw = reinterpret_cast<unsigned char *>(acc);
   uint32_t *const facts_w = reinterpret_cast<uint32_t *>(facts);
@@ -62,14 +62,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
   const int cb = a.cb;
   const int F = a.flat_waves;   // waves that stage a round
-  // lanes per term in a staging wave (1, 2 or 4): a staging lane writes the chunks k = sub, sub + G, ... of its term, so a
-  // term of <= G chunks costs every lane ONE strip write (a wave issues an instruction every 4+ cycles whatever the number
-  // of live lanes: the staging wave's instruction count is the round's critical path)
-  const int LOGG = a.flat_group_log2, G = 1 << LOGG;
-  const uint32_t sub = (uint32_t)ln & (uint32_t)(G - 1);
   const int A = NW - F;         // waves that add a round (those not staging in it)
   const int CAP = A * SLOTS;    // chunks per round
   const float rcpA = 1.0f / (float)A;
+  // lanes per term in a staging wave (1, 2 or 4): a staging lane writes the chunks k = sub, sub + G, ... of its term, so a
+  // term of <= 2 G chunks costs every lane two strip writes and no loop (a wave issues its instructions one after another
+  // whatever the number of live lanes: the staging wave's instruction count is on the round's critical path)
+  const int LOGG = a.flat_group_log2, G = 1 << LOGG;
+  const uint32_t sub = (uint32_t)ln & (uint32_t)(G - 1);
   const int tile = a.tile0 + blockIdx.x / a.n_chunks;
   const int chunk = blockIdx.x % a.n_chunks;
   const int v0 = chunk * a.q_chunk;
@@ -90,21 +90,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const __amdgpu_buffer_rsrc_t rs_po =
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.post_c + pbase), 0, (int)((pend - pbase) * 4), 0x00020000);
   constexpr uint32_t kOob = 0xfffffff0u;
+  constexpr uint32_t kRare = 0x80000000u;  // WaveWork::info: the round needs more than the register window (see strip_loads)
 
   for (int i = tid * 4; i < cb / APW + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
-  if (tid < 12) facts_w[tid] = 0;
+  if (tid < 8) facts_w[tid] = 0;
   unsigned long long my_visits = 0;
-  uint32_t wave_cands = 0, my_cands = 0;
+  uint32_t my_cands = 0;
 
   struct RowExt { int qb; int nnz; };  // as loaded: the low halves of the row's rowptr entries
   struct TermW { uint32_t term; float w, qs; bool valid; };
   struct Seg { uint32_t s, len; float w; };
   struct WaveWork {
-    int mc;            // chunks of the round dealt to this wave
+    uint32_t info;     // (scalar) chunks of the round dealt to this wave | kRare
     int rank;          // this wave's rank among the round's adding waves (< 0: it stages in that round)
-    uint32_t n_long;   // long segments of the round (swept by the whole workgroup)
-    bool direct;       // the round was flagged at staging: swept straight from the index
-    bool full_zero;    // the round ends with a whole-tile clear (long or direct sweeps, or a window that overflows)
+    uint32_t flags;    // (per lane, uniform) the round's flags as staged: bit 0 direct sweep, bits 1.. long segments
     apss_u32x2 pc[U];  // two coarse postings per lane and step
     float wq[U];       // query weight x cx_scale of the step's chunk
   };
@@ -145,87 +144,75 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     g.w = SHARD ? (t.qs > 0.f ? t.w * __builtin_amdgcn_rcpf(t.qs) : 0.f) : t.w;
     return g;
   };
-  unsigned long long fs[4] = {0, 0, 0, 0};  // (DIAG stamps inside the staging)
-  // staging of one round by one of its F waves
+  // Staging of one round by one of its F waves: a scan of the terms' chunk counts, the group shares its term's first
+  // index through a DPP move, and every lane writes at most two descriptors -- to the strip, or to its own spare entry when
+  // it has none (a select on the address, not an exec mask).  Everything unusual -- a long segment, a term of more than
+  // 2 G chunks, a round that does not fit -- takes one branch.
+  uint2 *const spare_item = strips + 3 * NW * SLOTS + ln;
   auto flatten = [&](const Seg &g, const int ring) {
     uint32_t len = g.len;
     my_visits += sub == 0u ? len : 0u;
-    bool bad = false;
-    const float w = g.w;
-    if (len > (uint32_t)kLongLen) {
-      if (sub == 0u) {
-        const uint32_t k = atomicAdd(&facts_w[4 * ring + 2], 1u);
+    const bool is_long = len > (uint32_t)kLongLen;
+    len = is_long ? 0u : len;
+    const uint32_t nch = (len + CH - 1) / CH;
+    // the term's first chunk index: a scan over the staging lanes plus ONE LDS atomic per wave on the round's counter (F > 1:
+    // the waves' ranges interleave in whatever order; a returning atomic per TERM on that one address measured 45 vs 32 ms)
+    const uint32_t mine = sub == 0u ? nch : 0u;  // a term counts once, in the first lane of its group
+    const uint32_t incl = wave_incl_scan(mine);
+    uint32_t base = 0;
+    if (ln == kWave - 1) base = atomicAdd(&facts_w[2 * ring], incl);
+    uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)base, kWave - 1) + incl - mine;
+    if (LOGG == 2) j0 = (uint32_t)__builtin_amdgcn_update_dpp((int)j0, (int)j0, 0x00, 0xf, 0xf, false);       // quad_perm [0,0,0,0]
+    else if (LOGG == 1) j0 = (uint32_t)__builtin_amdgcn_update_dpp((int)j0, (int)j0, 0xa0, 0xf, 0xf, false);  // quad_perm [0,0,2,2]
+    const uint32_t wbits = __float_as_uint(cxs * g.w);
+    uint2 *const st = strips + ring * (NW * SLOTS);
+    auto put = [&](const uint32_t k) {
+      // chunk j of the round -> adding wave j % A, slot j / A ((j + 0.5) / A is at least 1 / 2A away from an integer:
+      // the float quotient truncates exactly for j < 2^16)
+      const uint32_t j = min(j0 + k, (uint32_t)CAP - 1u);  // (a round that does not fit is flagged below; keep the store inside the strips)
+      const uint32_t sl = (uint32_t)(((float)j + 0.5f) * rcpA);
+      uint2 *const dst = k < nch ? st + (j - sl * (uint32_t)A) * SLOTS + sl : spare_item;
+      *dst = make_uint2((g.s + k * CH) * 4u, wbits);
+    };
+    const uint32_t two = LOGG == 0 ? 2u : 2u * (uint32_t)G;  // chunks per term written without the loop
+    put(sub);
+    put(sub + (uint32_t)(LOGG == 0 ? 1 : G));
+    const bool unfit = j0 + nch > (uint32_t)CAP;
+    if (__any(is_long || unfit || nch > two)) {
+      bool bad = unfit;
+      if (is_long && sub == 0u) {
+        const uint32_t k = atomicAdd(&facts_w[2 * ring + 1], 2u) >> 1;
         if (k < (uint32_t)LONGCAP) {
-          longs[ring * LONGCAP + k] = make_uint2(g.s, len);
-          long_w[ring * LONGCAP + k] = w;
+          longs[ring * LONGCAP + k] = make_uint2(g.s, g.len);
+          long_w[ring * LONGCAP + k] = g.w;
         } else {
           bad = true;
         }
       }
-      len = 0;
+      // the round is swept straight from the index; whatever was staged is ignored
+      if (bad) atomicOr(&facts_w[2 * ring + 1], 1u);
+      for (uint32_t k = two + sub; __any(k < nch); k += (uint32_t)G) put(k);
     }
-    const uint32_t nch = (len + CH - 1) / CH;
-    const uint32_t mine = sub == 0u ? nch : 0u;  // a term counts once, in the first lane of its group
-    if (DIAG) fs[0] = __builtin_readcyclecounter();
-    const uint32_t incl = wave_incl_scan(mine);
-    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-    uint32_t base = 0;
-    if (F == 1) {
-      if (ln == 0) facts_w[4 * ring] = tot;
-    } else {
-      uint32_t b = 0;
-      if (ln == 0) b = atomicAdd(&facts_w[4 * ring], tot);
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-    }
-    if (DIAG) fs[1] = __builtin_readcyclecounter();
-    bad |= base + tot > (uint32_t)CAP;
-    if (__any(bad)) {
-      if (ln == 0) facts_w[4 * ring + 1] = 1u;  // the round is swept straight from the index; whatever was staged is ignored
-      return;
-    }
-    uint32_t j0 = base + incl - mine;
-    if (G > 1) j0 = (uint32_t)__shfl((int)j0, ln & ~(G - 1));  // the group's first lane holds the term's first chunk index
-    const uint32_t wbits = __float_as_uint(cxs * w);
-    uint2 *const st = strips + ring * (NW * SLOTS);
-    auto put = [&](const uint32_t k) {
-      if (k < nch) {
-        // chunk j of the round -> adding wave j % A, slot j / A ((j + 0.5) / A is at least 1 / 2A away from an integer:
-        // the float quotient truncates exactly for j < 2^16)
-        const uint32_t j = j0 + k;
-        const uint32_t sl = (uint32_t)(((float)j + 0.5f) * rcpA);
-        st[(j - sl * (uint32_t)A) * SLOTS + sl] = make_uint2((g.s + k * CH) * 4u, wbits);
-      }
-    };
-    // (segments of up to 2 G chunks without the loop; G = 1: up to 3)
-    if (DIAG) fs[2] = __builtin_readcyclecounter();
-    put(sub);
-    put(sub + (uint32_t)G);
-    if (G == 1) put(2u);
-    const uint32_t done = G == 1 ? 3u : 2u * (uint32_t)G;
-    if (__any(nch > done))
-      for (uint32_t k = done + sub; __any(k < nch); k += (uint32_t)G) put(k);
-    if (DIAG) fs[3] = __builtin_readcyclecounter();
   };
-  // the next round of this wave, first half: its facts and its strip (LDS reads, issued ahead of the current round's adds so
-  // that one LDS round trip serves both)
-  struct StripRead { uint4 fc; uint2 it[U]; };
+  // the next round of this wave, first half: the round's facts and this wave's strip (LDS reads, issued ahead of the
+  // current round's adds so that one LDS round trip serves both)
+  struct StripRead { uint2 fc; uint2 it[U]; };
   auto strip_read = [&](StripRead &sr, const int ring, const int rank) {
     sr.fc = facts[ring];
     const uint2 *const st = strips + (ring * NW + max(rank, 0)) * SLOTS;
 #pragma unroll
     for (int u = 0; u < U; ++u) sr.it[u] = st[u * GPW + ln / LPC];
   };
-  // second half: every LPC lanes take one chunk of the strip and start its posting load
+  // second half: every LPC lanes take one chunk of the strip and start its posting load.  VALU only -- the one value the
+  // next round branches on (is it more than a register window?) goes to the scalar unit here, a round before its use.
   auto strip_loads = [&](WaveWork &f, StripRead &sr, const int rank) {
-    const bool direct = sr.fc.y != 0u;
-    const int tot = direct ? 0 : (int)sr.fc.x;
+    const uint32_t tot = (sr.fc.y & 1u) ? 0u : sr.fc.x;  // (a round flagged for the direct sweep has no chunks)
     // chunks j < tot with j % A == rank: ceil((tot - rank) / A)
-    const int mine = rank >= 0 && tot > rank ? (int)(((float)(tot - rank + A - 1) + 0.5f) * rcpA) : 0;
-    f.mc = __builtin_amdgcn_readfirstlane(mine);
+    const uint32_t mine = rank >= 0 && (int)tot > rank ? (uint32_t)(((float)((int)tot - rank + A - 1) + 0.5f) * rcpA) : 0u;
+    const bool rare = sr.fc.y != 0u || tot > (uint32_t)(A * WIN);
+    f.info = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mine | (rare ? kRare : 0u)));
     f.rank = rank;
-    f.direct = __builtin_amdgcn_readfirstlane((int)direct) != 0;
-    f.n_long = direct ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)min(sr.fc.z, (uint32_t)LONGCAP));
-    f.full_zero = f.direct || f.n_long > 0u || __builtin_amdgcn_readfirstlane(tot) > A * WIN;
+    f.flags = sr.fc.y;
 #pragma unroll
     for (int u = 0; u < U; ++u) asm volatile("" : "+v"(sr.it[u].x), "+v"(sr.it[u].y));
 #pragma unroll
@@ -233,7 +220,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       // a posting word of zero is no posting (segments are zero-padded to whole chunks; out-of-range reads return zero);
       // a strip slot past the wave's last chunk holds a stale descriptor: its load is sent out of range
       f.wq[u] = __uint_as_float(sr.it[u].y);
-      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, u * GPW + ln / LPC < f.mc ? sr.it[u].x + lo * 8u : kOob, 0, 0);
+      f.pc[u] = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (uint32_t)(u * GPW + ln / LPC) < mine ? sr.it[u].x + lo * 8u : kOob, 0, 0);
     }
   };
 
@@ -256,16 +243,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     strip_loads(wfa, sr, flat_index(v0 + 2) - F);
   }
 
-  // DIAG: cycle stamps of an adding wave's round, differenced at the end of the round (shares only)
-  unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
   auto round = [&](WaveWork &w0, WaveWork &w2, const int v, const int r0) {
-    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tw = 0;
-    if (DIAG) {
-      ts[0] = __builtin_readcyclecounter();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      tw = __builtin_readcyclecounter();
-    }
     const int r1 = r0 == 2 ? 0 : r0 + 1, r2 = r1 == 2 ? 0 : r1 + 1;
     const int q = v;
     constexpr int slack = 2;  // (k_probe_coarse: the soundness argument of the coarse threshold)
@@ -384,10 +362,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       {
         uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
         issue_batch(0, p0, p1, o0, o1);
+        // (nothing that waits for the strip or the facts may be scheduled ahead of the adds' issue)
+        asm volatile("" : "+v"(sr.fc.x), "+v"(sr.fc.y) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
         if (f5 < F) R5 = load_R(v + 5);
         if (f4 < F) In = load_I(R4, f4, v + 4);
         if (f3 < F) Pn = load_P(Ic);
-        if (DIAG) ts[1] = __builtin_readcyclecounter();
         strip_loads(w2, sr, rank1);
         check_batch(0, p0, p1, o0, o1);
       }
@@ -397,60 +377,67 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         issue_batch(u0, p0, p1, o0, o1);
         check_batch(u0, p0, p1, o0, o1);
       }
-      if (w0.mc > WIN) {  // chunks past the register window: straight from this wave's strip
+    }
+    Ic = In;
+    Pc = Pn;
+    const bool rare = (w0.info & kRare) != 0u;  // more than the register windows: one branch per round
+    bool full_zero = false;
+    if (rare) {
+      const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0.flags);
+      const int mc = (int)(w0.info & ~kRare);
+      full_zero = true;  // (long or direct sweeps, or chunks past the window: their postings are not in registers)
+      if (mc > WIN && w0.rank >= 0) {  // chunks past the register window: straight from this wave's strip
         const uint2 *const st = strips + (r0 * NW + w0.rank) * SLOTS;
-        for (int c0 = WIN; c0 < w0.mc; c0 += GPW) {
+        for (int c0 = WIN; c0 < mc; c0 += GPW) {
           const int c = c0 + ln / LPC;
           const uint2 it = st[min(c, SLOTS - 1)];
-          const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, c < w0.mc ? it.x + lo * 8u : kOob, 0, 0);
+          const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, c < mc ? it.x + lo * 8u : kOob, 0, 0);
           if (two.x) visit(two.x, __uint_as_float(it.y));
           if (two.y) visit(two.y, __uint_as_float(it.y));
         }
       }
-    }
-    Ic = In;
-    Pc = Pn;
-    if (w0.direct) {  // flagged at staging: every term straight from the index, one term per wave at a time
-      RowExt cur = load_R(v);
-      cur.nnz -= cur.qb;
-      cur.qb -= qbase_lo;
-      const float qsv = SHARD ? uniform_load(a.q_scale + v) : 1.0f;
-      const float iq = qsv > 0.f ? 1.0f / qsv : 0.f;
-      for (int k = wv; k < cur.nnz; k += NW) {
-        const uint32_t off = (uint32_t)(cur.qb + k) * 4u;
-        const uint32_t term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
-        const float wq_ = cxs * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0)) * iq;
-        const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, term * 8u, 0, 0);
-        for (uint32_t p = 2u * (uint32_t)ln; p < sg.y; p += 2u * kWave) {
-          const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sg.x + p) * 4u, 0, 0);
-          if (two.x) visit(two.x, wq_);
-          if (two.y && p + 1u < sg.y) visit(two.y, wq_);
+      if (flags & 1u) {  // flagged at staging: every term straight from the index, one term per wave at a time
+        RowExt cur = load_R(v);
+        cur.nnz -= cur.qb;
+        cur.qb -= qbase_lo;
+        const float qsv = SHARD ? uniform_load(a.q_scale + v) : 1.0f;
+        const float iq = qsv > 0.f ? 1.0f / qsv : 0.f;
+        for (int k = wv; k < cur.nnz; k += NW) {
+          const uint32_t off = (uint32_t)(cur.qb + k) * 4u;
+          const uint32_t term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
+          const float wq_ = cxs * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0)) * iq;
+          const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, term * 8u, 0, 0);
+          for (uint32_t p = 2u * (uint32_t)ln; p < sg.y; p += 2u * kWave) {
+            const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sg.x + p) * 4u, 0, 0);
+            if (two.x) visit(two.x, wq_);
+            if (two.y && p + 1u < sg.y) visit(two.y, wq_);
+          }
+        }
+      } else {
+        const uint32_t n_long = min(flags >> 1, (uint32_t)LONGCAP);
+        for (uint32_t j = 0; j < n_long; ++j) {
+          const uint2 sgm = longs[r0 * LONGCAP + j];
+          const float wq_ = cxs * long_w[r0 * LONGCAP + j];
+          uint32_t k = 2u * tid;
+          for (; k + 2u * BLOCK < sgm.y; k += 4u * BLOCK) {
+            const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+            const apss_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2u * BLOCK) * 4u, 0, 0);
+            visit(a0.x, wq_);
+            if (k + 1u < sgm.y) visit(a0.y, wq_);
+            visit(a1.x, wq_);
+            if (k + 2u * BLOCK + 1u < sgm.y) visit(a1.y, wq_);
+          }
+          for (; k < sgm.y; k += 2u * BLOCK) {
+            const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+            visit(a0.x, wq_);
+            if (k + 1u < sgm.y) visit(a0.y, wq_);
+          }
         }
       }
     }
-    for (uint32_t j = 0; j < w0.n_long; ++j) {
-      const uint2 sgm = longs[r0 * LONGCAP + j];
-      const float wq_ = cxs * long_w[r0 * LONGCAP + j];
-      uint32_t k = 2u * tid;
-      for (; k + 2u * BLOCK < sgm.y; k += 4u * BLOCK) {
-        const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-        const apss_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2u * BLOCK) * 4u, 0, 0);
-        visit(a0.x, wq_);
-        if (k + 1u < sgm.y) visit(a0.y, wq_);
-        visit(a1.x, wq_);
-        if (k + 2u * BLOCK + 1u < sgm.y) visit(a1.y, wq_);
-      }
-      for (; k < sgm.y; k += 2u * BLOCK) {
-        const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-        visit(a0.x, wq_);
-        if (k + 1u < sgm.y) visit(a0.y, wq_);
-      }
-    }
-    if (DIAG) ts[2] = __builtin_readcyclecounter();
     __syncthreads();  // every add of the round has landed
-    if (DIAG) ts[3] = __builtin_readcyclecounter();
 
-    if (w0.full_zero) {
+    if (full_zero) {
       for (int i = tid * 4; i < cb / APW; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
     } else if (f2 >= F) {
       unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
@@ -472,25 +459,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         }
       }
     }
-    if (tid == 0) facts[r0] = make_uint4(0u, 0u, 0u, 0u);  // (read one round ago; staged again in the next round)
-    if (DIAG) ts[4] = __builtin_readcyclecounter();
+    if (tid == 0) facts[r0] = make_uint2(0u, 0u);  // (read one round ago; staged again in the next round)
     __syncthreads();  // cleared: the next query starts from zero
-    if (DIAG) {
-      ts[5] = __builtin_readcyclecounter();
-      if (f2 >= F) {
-        for (int k = 1; k < 5; ++k) tsum[k] += ts[k + 1] - ts[k];
-        tsum[0] += ts[1] - tw;
-        tsum[5] += tw - ts[0];
-      } else {
-        tsum[6] += ts[2] - tw;
-        tsum[7] += 1;
-        tsum[8] += fs[0] - tw;     // loads of later rounds, strip read, chunk counts
-        tsum[9] += fs[1] - fs[0];  // scan + base
-        tsum[10] += fs[2] - fs[1]; // group broadcast
-        tsum[11] += fs[3] - fs[2]; // strip writes
-        tsum[12] += ts[2] - fs[3]; // next loads
-      }
-    }
 
     R4 = R5;
   };
@@ -502,13 +472,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     round(wfb, wfa, v + 1, r0);
     r0 = r0 == 2 ? 0 : r0 + 1;
   }
-  if (DIAG && ln == 0 && a.dbg)
-    for (int k = 0; k < 16; ++k) atomicAdd(&a.dbg[k], tsum[k]);
   __syncthreads();
   if (tid < 3) stat[tid] = 0;
   __syncthreads();
   atomicAdd(&stat[0], my_visits);
-  atomicAdd(&stat[1], (unsigned long long)my_cands + (ln == 0 ? wave_cands : 0u));
+  atomicAdd(&stat[1], (unsigned long long)my_cands);
   __syncthreads();
   if (tid == 0) {
     atomicAdd(&a.counters[kCtrVisits], stat[0]);

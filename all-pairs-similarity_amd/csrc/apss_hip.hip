@@ -1066,7 +1066,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     int flat_group_log2 = 2;
     while (flat_group_log2 > 0 && ceil_div(q_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
     const int64_t flat_waves = std::max<int64_t>(1, ceil_div(q_max_nnz, kWave >> flat_group_log2));
-    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 2) {
+    // (measured, C3: T = 8 shards 32.1 vs 40.5 ms, T = 4 57.1 vs 62.4; with one lane per term -- T = 2, 75-term rows; C5's
+    // 200-term rows -- the staging waves' serial work outweighs what the others save: 80.6 vs 77 ms, 343 vs 331 ms)
+    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_group_log2 >= 1 &&
+        flat_waves <= (int64_t)nw / 4) {
       CxVariant ev = cxv;
       ev.even = true;
       const double add_waves = nw - (double)flat_waves;               // a wave that stages a round adds nothing in it
@@ -1161,23 +1164,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     for (int64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_launch, ++n_launches) {
       a.tile0 = (int32_t)t0;
       a.n_tiles = (int32_t)std::min<int64_t>(tiles_per_launch, total_tiles - t0);
-      if (coarse_path && dbg.diag && cxv.even && cxv.block == 512 && cxv.u == 2 && cxv.shard && cxv.acc8 && !cxv.sgn) {
-        // diagnostic build of the thin-round instantiation: cycle stamps of a round's segments (shares only)
-        APSS_TRY(ensure(h, h->dbg, 16));
-        HIPCHK(h, hipMemsetAsync(h->dbg.p, 0, 16 * sizeof(unsigned long long), h->stream));
-        a.dbg = h->dbg.p;
-        hipLaunchKernelGGL((k_probe_even<512, 2, 128, true, false, true, true>), dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)),
-                           dim3(512), (size_t)dbg.pad_lds, h->stream, a);
-        HIPCHK(h, hipGetLastError());
-        unsigned long long d[16];
-        HIPCHK(h, hipMemcpyAsync(d, h->dbg.p, sizeof(d), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        const double ns = (double)std::max<unsigned long long>(1, d[7]), n = (double)a.n_tiles * a.nq * 8.0 - ns;
-        fprintf(stderr, "[apss diag even] per adding wave-round (cycle-counter ticks): wait for the postings %.0f | prods + issue of adds %.0f | "
-                        "LDS return, next loads, tests %.0f | barrier 1 %.0f | clears %.0f | barrier 2 %.0f || staging wave, after its loads arrived, to barrier 1: %.0f "
-                        "= loads + strip read %.0f + scan, base %.0f + broadcast %.0f + strip writes %.0f + next loads %.0f\n",
-                d[5] / n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[6] / ns, d[8] / ns, d[9] / ns, d[10] / ns, d[11] / ns, d[12] / ns);
-      } else if (coarse_path) {
+      if (coarse_path) {
         APSS_TRY(launch_cx(h, cxv, a));
       } else if (wave_path && dbg.diag) {
         // diagnostic build: in-kernel cycle stamps per round segment (shares only; never a benchmark number)
