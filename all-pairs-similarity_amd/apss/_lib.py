@@ -32,7 +32,7 @@ class Stats(C.Structure):
                 ("build_ms", C.c_double), ("probe_launches", C.c_int64), ("hbm_bytes", C.c_int64),
                 ("filter_survivors", C.c_int64), ("rescore_ms", C.c_double),
                 ("head_terms", C.c_int64), ("head_pairs", C.c_int64), ("head_survivors", C.c_int64),
-                ("head_ms", C.c_double), ("head_flops", C.c_double)]
+                ("head_ms", C.c_double), ("head_flops", C.c_double), ("thin_launches", C.c_int64)]
 
 
 def build(force=False):

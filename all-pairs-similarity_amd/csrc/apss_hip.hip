@@ -738,28 +738,19 @@ struct CxVariant {
 
 // k_probe_even's instantiations: (threads, window steps, shard rule, signed weights, 8-bit accumulators)
 #define APSS_EVEN_VARIANTS(X)          \
-  X(512, 5, false, false, false)       \
   X(512, 4, false, false, false)       \
   X(512, 3, false, false, false)       \
   X(512, 2, false, false, false)       \
-  X(512, 5, true, false, false)        \
   X(512, 4, true, false, false)        \
   X(512, 3, true, false, false)        \
   X(512, 2, true, false, false)        \
-  X(512, 5, true, false, true)         \
   X(512, 4, true, false, true)         \
   X(512, 3, true, false, true)         \
   X(512, 2, true, false, true)         \
-  X(512, 5, false, false, true)        \
   X(512, 4, false, false, true)        \
   X(512, 3, false, false, true)        \
   X(512, 2, false, false, true)        \
-  X(512, 5, false, true, false)        \
-  X(1024, 5, false, false, false)      \
   X(1024, 3, false, false, false)      \
-  X(1024, 5, false, true, false)       \
-  X(1024, 3, false, true, false)       \
-  X(1024, 5, false, false, true)       \
   X(1024, 3, false, false, true)
 
 bool cx_variant_exists(const CxVariant &v) {
@@ -894,6 +885,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.posting_visits = h->st.candidate_pairs = h->st.result_pairs = 0;
   h->st.probe_ms = 0;
   h->st.probe_launches = 0;
+  h->st.thin_launches = 0;
   h->st.head_pairs = h->st.head_survivors = 0;
   h->st.head_ms = h->st.head_flops = 0;
   h->st.head_terms = h->head_k ? (int64_t)h->head_terms.size() : 0;
@@ -1076,9 +1068,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       const double cpt = std::max(1.0, seg / 16.0 + 0.5);           // chunks per term
       const double round_chunks = q_terms * cpt + 3.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
       int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
-      const bool fits = ue <= 5;  // (a window that overflows most rounds pays a whole-tile clear each time)
-      ue = cxv.block == 1024 ? (ue <= 3 ? 3 : 5) : std::max(2, std::min(5, ue));
-      if (cxv.sgn) ue = 5;
+      // (a window that overflows most rounds pays a whole-tile clear each time; thin rounds only: windows of <= 4 steps)
+      const bool fits = ue <= (cxv.block == 1024 ? 3 : 4) && !cxv.sgn;
+      ue = cxv.block == 1024 ? 3 : std::max(2, ue);
       ev.u = ue;
       if (fits && cx_variant_exists(ev)) {
         cxv = ev;
@@ -1160,12 +1152,13 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     a.res_cap = h->res_q.cap;
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    int64_t n_launches = 0;
+    int64_t n_launches = 0, thin_launches = 0;
     for (int64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_launch, ++n_launches) {
       a.tile0 = (int32_t)t0;
       a.n_tiles = (int32_t)std::min<int64_t>(tiles_per_launch, total_tiles - t0);
       if (coarse_path) {
         APSS_TRY(launch_cx(h, cxv, a));
+        thin_launches += cxv.even ? 1 : 0;
       } else if (wave_path && dbg.diag) {
         // diagnostic build: in-kernel cycle stamps per round segment (shares only; never a benchmark number)
         APSS_TRY(ensure(h, h->dbg, 8));
@@ -1212,6 +1205,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->st.probe_ms += ms;
     h->st.probe_launches += n_launches;
+    h->st.thin_launches += thin_launches;
     h->st.posting_visits = (int64_t)c[kCtrVisits];
     h->st.candidate_pairs = (int64_t)c[kCtrCands];
     // the speed paths count a stored query's touch of its own slot; it is not a (q, c != q) pair

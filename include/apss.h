@@ -92,6 +92,8 @@ typedef struct apss_stats {
   int64_t head_survivors;   /* pairs the dense filter passed on to exact rescoring */
   double head_ms;           /* device time of the dense-head kernel, HIP events */
   double head_flops;        /* 2 * KH * (query slots x candidate rows actually multiplied) of the last call */
+  int64_t thin_launches;    /* probe launches of the last call that took the thin-round filter kernel (k_probe_even: a term
+                               shard's or a sparse batch's rounds of a few hundred postings) */
 } apss_stats;
 
 /* ---- lifetime (actor construction / stop, IWA:21-39) ---- */
