@@ -187,7 +187,7 @@ class ShardedJoin:
             if self.world > 1:
                 dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             self.last = {
-                "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0),
+                "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
                 "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
                 "exchange": {"term_shards": 1, "candidate_ranges": self.D, "candidates_per_rank": [int(n_mine)],
                              "union": int(n_mine), "all_gather_bytes_per_rank": 0, "all_reduce_bytes": 0,
@@ -222,7 +222,7 @@ class ShardedJoin:
         if self.world > 1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         self.last = {
-            "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0),
+            "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
             "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
             "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes,
                          "union": int(uniq.numel()), "all_gather_bytes_per_rank": 8 * max(sizes + [1]) * self.T,

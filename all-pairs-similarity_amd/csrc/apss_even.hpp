@@ -174,9 +174,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       uint2 *const dst = k < nch ? st + (j - sl * (uint32_t)A) * SLOTS + sl : spare_item;
       *dst = make_uint2((g.s + k * CH) * 4u, wbits);
     };
-    const uint32_t two = LOGG == 0 ? 2u : 2u * (uint32_t)G;  // chunks per term written without the loop
+    // chunks per term written without the loop: 8 with four lanes per term (two writes each), 6 with two, 3 with one
+    const uint32_t two = LOGG == 2 ? 8u : (LOGG == 1 ? 6u : 3u);
     put(sub);
-    put(sub + (uint32_t)(LOGG == 0 ? 1 : G));
+    put(sub + (uint32_t)G);
+    if (LOGG < 2) put(sub + 2u * (uint32_t)G);
     const bool unfit = j0 + nch > (uint32_t)CAP;
     if (__any(is_long || unfit || nch > two)) {
       bool bad = unfit;

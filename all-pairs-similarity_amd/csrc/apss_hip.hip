@@ -48,6 +48,7 @@ struct DebugCfg {
   int tiles_per_launch = 0;    // tiles_per_launch=N
   bool no_tail = false;        // no_tail        every insert extends the tile index at once (no tail of waiting rows)
   bool no_acc8 = false;        // no_acc8        term shards keep 16-bit accumulators over 32768-row tiles
+  int flat_group = -1;         // flat_group=L   k_probe_even: 2^L staging lanes per term (default: as many as keep the staging waves <= 1/4)
   int pad_lds = 0;             // pad_lds=N      N bytes of dynamic LDS on the filter launch (occupancy experiments)
   bool no_even = false;        // no_even        the filter stages every round on all waves (k_probe_coarse), never on F of them (k_probe_even)
   int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
@@ -83,6 +84,7 @@ DebugCfg parse_debug_env() {
     else if (key == "no_acc8") d.no_acc8 = val != 0;
     else if (key == "no_even") d.no_even = val != 0;
     else if (key == "pad_lds") d.pad_lds = (int)val;
+    else if (key == "flat_group") d.flat_group = (int)val;
     else if (key == "seg_align") d.seg_align = val;
     else if (key == "bank_order") d.bank_order = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
@@ -1057,6 +1059,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     // staging lanes per term: as many as keep the staging waves at <= a quarter of the workgroup
     int flat_group_log2 = 2;
     while (flat_group_log2 > 0 && ceil_div(q_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
+    if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
     const int64_t flat_waves = std::max<int64_t>(1, ceil_div(q_max_nnz, kWave >> flat_group_log2));
     // (measured, C3: T = 8 shards 32.1 vs 40.5 ms, T = 4 57.1 vs 62.4; with one lane per term -- T = 2, 75-term rows; C5's
     // 200-term rows -- the staging waves' serial work outweighs what the others save: 80.6 vs 77 ms, 343 vs 331 ms)

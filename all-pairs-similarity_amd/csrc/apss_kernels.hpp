@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   constexpr int CBMAX = WIDE ? 131072 : (BLOCK <= 512 && !ACC8 ? 32768 : 65536);
   constexpr int APW = 32 / (int)ABITS;  // accumulators per LDS word
   __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / APW + kWave];  // two u16 / four u8 accumulators per word (+ slack)
-  __shared__ uint2 items[NW * WIN];        // [NW][WIN] {byte offset of the chunk's first posting, weight bits}
+  __shared__ uint2 items[NW * WIN + kWave];  // [NW][WIN] {byte offset of the chunk's first posting, weight bits} (+ one spare entry per lane)
   __shared__ uint2 longs[3 * LONGCAP];     // [3][LONGCAP]
   __shared__ float long_w[3 * LONGCAP];    // [3][LONGCAP]
   __shared__ uint32_t surv[SURVCAP];
@@ -1467,9 +1467,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       if (k < nch && excl + k < (uint32_t)WIN)
         wl[excl + k] = make_uint2((g.s + k * CH) * 4u, wbits);  // {byte offset of the chunk's first posting, weight bits}
     };
+    // the first chunks of every segment without exec masks: a lane with no such chunk writes its own spare entry (a select
+    // on the address; a mask is a trip through the scalar unit, ~64 cycles of the wave's serial issue each)
+    auto put_always = [&](const uint32_t k) {
+      uint2 *const dst = k < nch && excl + k < (uint32_t)WIN ? wl + excl + k : items + NW * WIN + ln;
+      *dst = make_uint2((g.s + k * CH) * 4u, wbits);
+    };
     constexpr uint32_t kPuts = CH == 16 ? 3u : 5u;  // covers segments of up to 48 / 40 postings without the loop
 #pragma unroll
-    for (uint32_t k = 0; k < kPuts; ++k) put(k);
+    for (uint32_t k = 0; k < kPuts; ++k) put_always(k);
     if (__any(nch > kPuts))
       for (uint32_t k = kPuts; __any(k < nch && excl + k < (uint32_t)WIN); ++k) put(k);
   };

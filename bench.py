@@ -166,6 +166,8 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
     hybrid = st["head_terms"] > 0
     filter_kernel = "k_probe_coarse (16-bit LDS accumulators, 4-B postings) + k_rescore" if st["filter_survivors"] or not visits \
         else "k_probe_wave / k_probe"
+    if st.get("thin_launches"):
+        filter_kernel = "k_probe_even (thin rounds: staging by F waves, chunks dealt evenly; 4-B postings) + k_rescore"
     out = {
         "value": cands / sec_per_step,
         "ms_per_step": sec_per_step * 1e3,
@@ -293,7 +295,7 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
                             "per step: all-reduce of counters only (result sets of different candidate ranges are disjoint)"),
         }
         visits = sj.last["posting_visits"]
-        row["roofline"] = {"bound": "lds", "kernel": "k_probe_coarse<SHARD>" if sj.T > 1 else "k_probe_coarse",
+        row["roofline"] = {"bound": "lds", "kernel": ("k_probe_even" if sj.last.get("thin_launches") else "k_probe_coarse") + ("<SHARD>" if sj.T > 1 else ""),
                            "achieved": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 if pm > 0 else None,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s (per GPU: slowest shard's kernel, 1/N of the job's 8-B posting visits)",
                            "frac": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS if pm > 0 else None,
