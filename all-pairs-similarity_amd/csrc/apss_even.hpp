@@ -102,7 +102,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   struct Seg { uint32_t s, len; float w; };
   struct WaveWork {
     uint32_t info;     // (scalar) chunks of the round dealt to this wave | kRare
-    int rank;          // this wave's rank among the round's adding waves (< 0: it stages in that round)
     uint32_t flags;    // (per lane, uniform) the round's flags as staged: bit 0 direct sweep, bits 1.. long segments
     apss_u32x2 pc[U];  // two coarse postings per lane and step
     float wq[U];       // query weight x cx_scale of the step's chunk
@@ -122,8 +121,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     r.nnz = rowptr_lo[2 * vv + 2];
     return r;
   };
-  // the staging waves of round t: (t + i) % NW, i < F; wave w is the i-th when (w - t) % NW == i
-  auto flat_index = [&](const int t) { return (wv - t) & (NW - 1); };
   auto load_I = [&](const RowExt &r, const int fi, const int v) {
     TermW t;
     const int kterm = ((fi * kWave) >> LOGG) + (ln >> LOGG);
@@ -201,7 +198,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   struct StripRead { uint2 fc; uint2 it[U]; };
   auto strip_read = [&](StripRead &sr, const int ring, const int rank) {
     sr.fc = facts[ring];
-    const uint2 *const st = strips + (ring * NW + max(rank, 0)) * SLOTS;
+    const uint2 *const st = strips + (ring * NW + rank) * SLOTS;
 #pragma unroll
     for (int u = 0; u < U; ++u) sr.it[u] = st[u * GPW + ln / LPC];
   };
@@ -210,10 +207,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   auto strip_loads = [&](WaveWork &f, StripRead &sr, const int rank) {
     const uint32_t tot = (sr.fc.y & 1u) ? 0u : sr.fc.x;  // (a round flagged for the direct sweep has no chunks)
     // chunks j < tot with j % A == rank: ceil((tot - rank) / A)
-    const uint32_t mine = rank >= 0 && (int)tot > rank ? (uint32_t)(((float)((int)tot - rank + A - 1) + 0.5f) * rcpA) : 0u;
+    const uint32_t mine = (int)tot > rank ? (uint32_t)(((float)((int)tot - rank + A - 1) + 0.5f) * rcpA) : 0u;
     const bool rare = sr.fc.y != 0u || tot > (uint32_t)(A * WIN);
     f.info = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mine | (rare ? kRare : 0u)));
-    f.rank = rank;
     f.flags = sr.fc.y;
 #pragma unroll
     for (int u = 0; u < U; ++u) asm volatile("" : "+v"(sr.it[u].x), "+v"(sr.it[u].y));
@@ -226,151 +222,159 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     }
   };
 
-  RowExt R4 = load_R(v0 + 4);   // extent of row v + 4 at the top of round v (staging waves of that round only)
-  TermW Ic;   // terms of round v + 3 (when this wave stages it)
-  Seg Pc;     // descriptors of round v + 2
+  // FIXED ROLES: waves 0 .. F-1 stage every round and never add, waves F .. NW-1 add every round and never stage.  The two
+  // kinds run their own loops (same two barriers per round): no per-round role arithmetic on the scalar unit, and the
+  // compiler allocates registers for one job at a time.
+  const bool stager = wv < F;
+  const int rank = wv - F;  // an adding wave's rank
   WaveWork wfa, wfb;
+  constexpr int slack = 2;  // (k_probe_coarse: the soundness argument of the coarse threshold)
+  const int thr_c = (int)a.cx_theta - slack;
+  const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
   {
-    const TermW I0 = load_I(load_R(v0), flat_index(v0), v0), I1 = load_I(load_R(v0 + 1), flat_index(v0 + 1), v0 + 1),
-                I2 = load_I(load_R(v0 + 2), flat_index(v0 + 2), v0 + 2);
-    Ic = load_I(load_R(v0 + 3), flat_index(v0 + 3), v0 + 3);
+    // rounds v0 and v0 + 1 are staged before the loops start
+    const TermW I0 = load_I(load_R(v0), wv, v0), I1 = load_I(load_R(v0 + 1), wv, v0 + 1);
     const Seg P0 = load_P(I0), P1 = load_P(I1);
-    Pc = load_P(I2);
     __syncthreads();
-    if (flat_index(v0) < F) flatten(P0, 0);
-    if (flat_index(v0 + 1) < F) flatten(P1, 1);
+    if (stager) {
+      flatten(P0, 0);
+      flatten(P1, 1);
+    }
     __syncthreads();
-    StripRead sr;
-    strip_read(sr, 0, flat_index(v0 + 2) - F);
-    strip_loads(wfa, sr, flat_index(v0 + 2) - F);
+    if (!stager) {
+      StripRead sr;
+      strip_read(sr, 0, rank);
+      strip_loads(wfa, sr, rank);
+    }
   }
 
-  auto round = [&](WaveWork &w0, WaveWork &w2, const int v, const int r0) {
-    const int r1 = r0 == 2 ? 0 : r0 + 1, r2 = r1 == 2 ? 0 : r1 + 1;
-    const int q = v;
-    constexpr int slack = 2;  // (k_probe_coarse: the soundness argument of the coarse threshold)
-    const int thr_c = (int)a.cx_theta - slack;
-    const uint32_t thr1 = (uint32_t)max(thr_c, 1) - 1u;
-    RowExt R5 = R4;  // the extent of row v + 5, loaded by the waves that will stage that round, used a round later
-    const int f5 = flat_index(v + 5);
-
-    // a crossing, reported by the wave that sees it (uniform control flow: one global atomic per wave and call)
-    auto report = [&](const bool cross, const uint32_t slot, const uint32_t sum) {
-      bool ok = cross;
-      if (ok) ok = a.ext_id[tile_row0 + slot] != a.q_ext[q];
-      const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
-      if (ok && o < a.res_cap) {
-        a.res_q[o] = q;
-        a.res_c[o] = (int32_t)(tile_row0 + slot);
-        a.res_s[o] = (float)sum / cxs;  // coarse score at the crossing, replaced by k_rescore
-      }
-    };
-    // the same from divergent control flow (sweeps): one atomic per lane
-    auto report_lane = [&](const uint32_t slot, const uint32_t sum) {
-      if (a.ext_id[tile_row0 + slot] != a.q_ext[q]) {
-        const uint64_t o = atomicAdd(&a.counters[kCtrResults], 1ull);
-        if (o < a.res_cap) {
+  if (stager) {
+    // ---- staging waves: round v loads the row extent of v + 5, the terms of v + 4, the descriptors of v + 3 and
+    // stages v + 2 (every value is used a round after its load) ----
+    RowExt R4 = load_R(v0 + 4);
+    TermW Ic = load_I(load_R(v0 + 3), wv, v0 + 3);
+    Seg Pc = load_P(load_I(load_R(v0 + 2), wv, v0 + 2));
+    int r0 = 0;
+    for (int v = v0; v < v1; ++v) {
+      const int r2 = r0 == 0 ? 2 : r0 - 1;  // (v + 2) % 3
+      const RowExt R5 = load_R(v + 5);
+      const TermW In = load_I(R4, wv, v + 4);
+      const Seg Pn = load_P(Ic);
+      flatten(Pc, r2);
+      __syncthreads();  // every add of the round has landed
+      if (tid == 0) facts[r0] = make_uint2(0u, 0u);  // (read one round ago; staged again in the next round)
+      __syncthreads();  // cleared: the next query starts from zero
+      R4 = R5;
+      Ic = In;
+      Pc = Pn;
+      r0 = r0 == 2 ? 0 : r0 + 1;
+    }
+  } else {
+    // ---- adding waves ----
+    const int atid = tid - F * kWave, ABLOCK = A * kWave;  // thread index / count among the adding waves (sweeps, whole-tile clears)
+    auto round = [&](WaveWork &w0, WaveWork &w2, const int v, const int r0) {
+      const int r1 = r0 == 2 ? 0 : r0 + 1;
+      const int q = v;
+      // a crossing, reported by the wave that sees it (uniform control flow: one global atomic per wave and call)
+      auto report = [&](const bool cross, const uint32_t slot, const uint32_t sum) {
+        bool ok = cross;
+        if (ok) ok = a.ext_id[tile_row0 + slot] != a.q_ext[q];
+        const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
+        if (ok && o < a.res_cap) {
           a.res_q[o] = q;
           a.res_c[o] = (int32_t)(tile_row0 + slot);
-          a.res_s[o] = (float)sum / cxs;
+          a.res_s[o] = (float)sum / cxs;  // coarse score at the crossing, replaced by k_rescore
         }
-      }
-    };
-    auto slot_of = [&](const uint32_t pcw) { return WIDE ? pcw >> 15 : (SLOT2 && !ACC8 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu); };
-    auto prod = [&](const uint32_t pcw, const float wqs) {
-      const float x = __builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(WIDE ? pcw & 0x7fffu : pcw >> 16))), 1.0f);
-      return SIGNED ? (uint32_t)max((int)x, 1) : (uint32_t)x;
-    };
-    auto add16 = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
-      if (WIDE) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + ((pcw >> 15) & 0x1fffcu)), p << ((pcw >> 12) & 24u));
-      if (SLOT2) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw & 0xfffcu)), p << ((pcw << 3) & 31u));
-      const uint32_t slot = pcw & 0xffffu;
-      return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));
-    };
-    auto half_of = [&](const uint32_t old_word, const uint32_t pcw) {
-      if (WIDE) return __builtin_amdgcn_ubfe(old_word, (pcw >> 12) & 24u, 8u);
-      return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, ABITS) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
-    };
-    auto visit = [&](const uint32_t pcw, const float wqs) {  // (sweeps: divergent control flow)
-      const uint32_t p = prod(pcw, wqs);
-      const uint32_t old16 = half_of(add16(pcw, p), pcw);
-      my_cands += old16 == 0u ? 1u : 0u;
-      if (thr1 - old16 < p) report_lane(slot_of(pcw), old16 + p);
-    };
-    constexpr int BATCH = 3;
-    // An idle lane (zero word) adds into ITS OWN spare word behind the accumulators (a select on the address) instead of
-    // being masked off: an exec mask around each atomic is a trip VALU -> scalar unit -> VALU (compare, s_and_saveexec,
-    // s_or) that cost ~64 cycles of the wave's serial issue per posting slot (profiles/microbench/issue_rate.hip).  Its
-    // "old value" is replaced by thr1 + 1 afterwards: never a first touch (not 0), never a crossing (thr1 - old wraps).
-    const uint32_t spare = (uint32_t)(CBMAX / APW) * 4u + (uint32_t)ln * 4u;
-    auto add_or_spare = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
-      const uint32_t addr = WIDE ? (pcw >> 15) & 0x1fffcu : (SLOT2 ? pcw & 0xfffcu : ((pcw & 0xffffu) >> 1) * 4u);
-      const uint32_t sh = WIDE ? (pcw >> 12) & 24u : (SLOT2 ? (pcw << 3) & 31u : (pcw & 1u) << 4);
-      return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw ? addr : spare)), p << sh);
-    };
-    auto issue_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int u = u0 + j;
-        if (u < U) {
-          p0[j] = prod(w0.pc[u].x, w0.wq[u]);
-          p1[j] = prod(w0.pc[u].y, w0.wq[u]);
-          o0[j] = add_or_spare(w0.pc[u].x, p0[j]);
-          o1[j] = add_or_spare(w0.pc[u].y, p1[j]);
+      };
+      // the same from divergent control flow (sweeps): one atomic per lane
+      auto report_lane = [&](const uint32_t slot, const uint32_t sum) {
+        if (a.ext_id[tile_row0 + slot] != a.q_ext[q]) {
+          const uint64_t o = atomicAdd(&a.counters[kCtrResults], 1ull);
+          if (o < a.res_cap) {
+            a.res_q[o] = q;
+            a.res_c[o] = (int32_t)(tile_row0 + slot);
+            a.res_s[o] = (float)sum / cxs;
+          }
         }
-      }
-    };
-    auto check_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
-      // first touches and crossings are counted per lane (VALU only); one trip to the scalar unit per batch decides
-      // whether any lane crossed
-      uint32_t n_cross = 0;
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        const int u = u0 + j;
-        if (u < U) {
-          o0[j] = w0.pc[u].x ? half_of(o0[j], w0.pc[u].x) : thr1 + 1u;
-          o1[j] = w0.pc[u].y ? half_of(o1[j], w0.pc[u].y) : thr1 + 1u;
-          my_cands += (o0[j] == 0u ? 1u : 0u) + (o1[j] == 0u ? 1u : 0u);
-          n_cross += (thr1 - o0[j] < p0[j] ? 1u : 0u) + (thr1 - o1[j] < p1[j] ? 1u : 0u);
-        }
-      }
-      if (__any(n_cross != 0u)) {
+      };
+      auto slot_of = [&](const uint32_t pcw) { return WIDE ? pcw >> 15 : (SLOT2 && !ACC8 ? (pcw & 0xffffu) >> 1 : pcw & 0xffffu); };
+      auto prod = [&](const uint32_t pcw, const float wqs) {
+        const float x = __builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(WIDE ? pcw & 0x7fffu : pcw >> 16))), 1.0f);
+        return SIGNED ? (uint32_t)max((int)x, 1) : (uint32_t)x;
+      };
+      auto add16 = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
+        if (WIDE) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + ((pcw >> 15) & 0x1fffcu)), p << ((pcw >> 12) & 24u));
+        if (SLOT2) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw & 0xfffcu)), p << ((pcw << 3) & 31u));
+        const uint32_t slot = pcw & 0xffffu;
+        return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));
+      };
+      auto half_of = [&](const uint32_t old_word, const uint32_t pcw) {
+        if (WIDE) return __builtin_amdgcn_ubfe(old_word, (pcw >> 12) & 24u, 8u);
+        return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, ABITS) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
+      };
+      auto visit = [&](const uint32_t pcw, const float wqs) {  // (sweeps: divergent control flow)
+        const uint32_t p = prod(pcw, wqs);
+        const uint32_t old16 = half_of(add16(pcw, p), pcw);
+        my_cands += old16 == 0u ? 1u : 0u;
+        if (thr1 - old16 < p) report_lane(slot_of(pcw), old16 + p);
+      };
+      constexpr int BATCH = 3;
+      // An idle lane (zero word) adds into ITS OWN spare word behind the accumulators (a select on the address) instead of
+      // being masked off: an exec mask around each atomic is a trip VALU -> scalar unit -> VALU (compare, s_and_saveexec,
+      // s_or) that cost ~64 cycles of the wave's serial issue per posting slot (profiles/microbench/issue_rate.hip).  Its
+      // "old value" is replaced by thr1 + 1 afterwards: never a first touch (not 0), never a crossing (thr1 - old wraps).
+      const uint32_t spare = (uint32_t)(CBMAX / APW) * 4u + (uint32_t)ln * 4u;
+      auto add_or_spare = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
+        const uint32_t addr = WIDE ? (pcw >> 15) & 0x1fffcu : (SLOT2 ? pcw & 0xfffcu : ((pcw & 0xffffu) >> 1) * 4u);
+        const uint32_t sh = WIDE ? (pcw >> 12) & 24u : (SLOT2 ? (pcw << 3) & 31u : (pcw & 1u) << 4);
+        return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw ? addr : spare)), p << sh);
+      };
+      auto issue_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
           const int u = u0 + j;
           if (u < U) {
-            report(thr1 - o0[j] < p0[j], slot_of(w0.pc[u].x), o0[j] + p0[j]);
-            report(thr1 - o1[j] < p1[j], slot_of(w0.pc[u].y), o1[j] + p1[j]);
+            p0[j] = prod(w0.pc[u].x, w0.wq[u]);
+            p1[j] = prod(w0.pc[u].y, w0.wq[u]);
+            o0[j] = add_or_spare(w0.pc[u].x, p0[j]);
+            o1[j] = add_or_spare(w0.pc[u].y, p1[j]);
           }
         }
-      }
-    };
-    // a wave that stages round v + 2 adds nothing in round v (no chunk of round v was dealt to it): the staging is off
-    // the adding waves' path to the barrier
-    const int f4 = flat_index(v + 4), f3 = flat_index(v + 3), f2 = flat_index(v + 2);
-    const int rank1 = f3 - F;  // this wave's rank among the adding waves of round v + 1 (which stages round v + 3)
-    TermW In = Ic;
-    Seg Pn = Pc;
-    StripRead sr;
-    if (f2 < F) {
-      if (f5 < F) R5 = load_R(v + 5);
-      if (f4 < F) In = load_I(R4, f4, v + 4);
-      if (f3 < F) Pn = load_P(Ic);
-      strip_read(sr, r1, rank1);
-      flatten(Pc, r2);
-      strip_loads(w2, sr, rank1);
-    } else {
-      strip_read(sr, r1, rank1);
+      };
+      auto check_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
+        // first touches and crossings are counted per lane (VALU only); one trip to the scalar unit per batch decides
+        // whether any lane crossed
+        uint32_t n_cross = 0;
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int u = u0 + j;
+          if (u < U) {
+            o0[j] = w0.pc[u].x ? half_of(o0[j], w0.pc[u].x) : thr1 + 1u;
+            o1[j] = w0.pc[u].y ? half_of(o1[j], w0.pc[u].y) : thr1 + 1u;
+            my_cands += (o0[j] == 0u ? 1u : 0u) + (o1[j] == 0u ? 1u : 0u);
+            n_cross += (thr1 - o0[j] < p0[j] ? 1u : 0u) + (thr1 - o1[j] < p1[j] ? 1u : 0u);
+          }
+        }
+        if (__any(n_cross != 0u)) {
+#pragma unroll
+          for (int j = 0; j < BATCH; ++j) {
+            const int u = u0 + j;
+            if (u < U) {
+              report(thr1 - o0[j] < p0[j], slot_of(w0.pc[u].x), o0[j] + p0[j]);
+              report(thr1 - o1[j] < p1[j], slot_of(w0.pc[u].y), o1[j] + p1[j]);
+            }
+          }
+        }
+      };
+      StripRead sr;
+      strip_read(sr, r1, rank);
       {
         uint32_t p0[BATCH], p1[BATCH], o0[BATCH], o1[BATCH];
         issue_batch(0, p0, p1, o0, o1);
         // (nothing that waits for the strip or the facts may be scheduled ahead of the adds' issue)
         asm volatile("" : "+v"(sr.fc.x), "+v"(sr.fc.y) : : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (f5 < F) R5 = load_R(v + 5);
-        if (f4 < F) In = load_I(R4, f4, v + 4);
-        if (f3 < F) Pn = load_P(Ic);
-        strip_loads(w2, sr, rank1);
+        strip_loads(w2, sr, rank);
         check_batch(0, p0, p1, o0, o1);
       }
 #pragma unroll
@@ -379,100 +383,84 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         issue_batch(u0, p0, p1, o0, o1);
         check_batch(u0, p0, p1, o0, o1);
       }
-    }
-    Ic = In;
-    Pc = Pn;
-    const bool rare = (w0.info & kRare) != 0u;  // more than the register windows: one branch per round
-    bool full_zero = false;
-    if (rare) {
-      const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0.flags);
-      const int mc = (int)(w0.info & ~kRare);
-      full_zero = true;  // (long or direct sweeps, or chunks past the window: their postings are not in registers)
-      if (mc > WIN && w0.rank >= 0) {  // chunks past the register window: straight from this wave's strip
-        const uint2 *const st = strips + (r0 * NW + w0.rank) * SLOTS;
-        for (int c0 = WIN; c0 < mc; c0 += GPW) {
-          const int c = c0 + ln / LPC;
-          const uint2 it = st[min(c, SLOTS - 1)];
-          const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, c < mc ? it.x + lo * 8u : kOob, 0, 0);
-          if (two.x) visit(two.x, __uint_as_float(it.y));
-          if (two.y) visit(two.y, __uint_as_float(it.y));
-        }
-      }
-      if (flags & 1u) {  // flagged at staging: every term straight from the index, one term per wave at a time
-        RowExt cur = load_R(v);
-        cur.nnz -= cur.qb;
-        cur.qb -= qbase_lo;
-        const float qsv = SHARD ? uniform_load(a.q_scale + v) : 1.0f;
-        const float iq = qsv > 0.f ? 1.0f / qsv : 0.f;
-        for (int k = wv; k < cur.nnz; k += NW) {
-          const uint32_t off = (uint32_t)(cur.qb + k) * 4u;
-          const uint32_t term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
-          const float wq_ = cxs * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0)) * iq;
-          const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, term * 8u, 0, 0);
-          for (uint32_t p = 2u * (uint32_t)ln; p < sg.y; p += 2u * kWave) {
-            const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sg.x + p) * 4u, 0, 0);
-            if (two.x) visit(two.x, wq_);
-            if (two.y && p + 1u < sg.y) visit(two.y, wq_);
+      const bool rare = (w0.info & kRare) != 0u;  // more than the register windows: one branch per round
+      if (rare) {
+        const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0.flags);
+        const int mc = (int)(w0.info & ~kRare);
+        if (mc > WIN) {  // chunks past the register window: straight from this wave's strip
+          const uint2 *const st = strips + (r0 * NW + rank) * SLOTS;
+          for (int c0 = WIN; c0 < mc; c0 += GPW) {
+            const int c = c0 + ln / LPC;
+            const uint2 it = st[min(c, SLOTS - 1)];
+            const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, c < mc ? it.x + lo * 8u : kOob, 0, 0);
+            if (two.x) visit(two.x, __uint_as_float(it.y));
+            if (two.y) visit(two.y, __uint_as_float(it.y));
           }
         }
-      } else {
-        const uint32_t n_long = min(flags >> 1, (uint32_t)LONGCAP);
-        for (uint32_t j = 0; j < n_long; ++j) {
-          const uint2 sgm = longs[r0 * LONGCAP + j];
-          const float wq_ = cxs * long_w[r0 * LONGCAP + j];
-          uint32_t k = 2u * tid;
-          for (; k + 2u * BLOCK < sgm.y; k += 4u * BLOCK) {
-            const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-            const apss_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2u * BLOCK) * 4u, 0, 0);
-            visit(a0.x, wq_);
-            if (k + 1u < sgm.y) visit(a0.y, wq_);
-            visit(a1.x, wq_);
-            if (k + 2u * BLOCK + 1u < sgm.y) visit(a1.y, wq_);
+        if (flags & 1u) {  // flagged at staging: every term straight from the index, one term per adding wave at a time
+          RowExt cur = load_R(v);
+          cur.nnz -= cur.qb;
+          cur.qb -= qbase_lo;
+          const float qsv = SHARD ? uniform_load(a.q_scale + v) : 1.0f;
+          const float iq = qsv > 0.f ? 1.0f / qsv : 0.f;
+          for (int k = rank; k < cur.nnz; k += A) {
+            const uint32_t off = (uint32_t)(cur.qb + k) * 4u;
+            const uint32_t term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
+            const float wq_ = cxs * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0)) * iq;
+            const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, term * 8u, 0, 0);
+            for (uint32_t p = 2u * (uint32_t)ln; p < sg.y; p += 2u * kWave) {
+              const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sg.x + p) * 4u, 0, 0);
+              if (two.x) visit(two.x, wq_);
+              if (two.y && p + 1u < sg.y) visit(two.y, wq_);
+            }
           }
-          for (; k < sgm.y; k += 2u * BLOCK) {
-            const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-            visit(a0.x, wq_);
-            if (k + 1u < sgm.y) visit(a0.y, wq_);
-          }
-        }
-      }
-    }
-    __syncthreads();  // every add of the round has landed
-
-    if (full_zero) {
-      for (int i = tid * 4; i < cb / APW; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
-    } else if (f2 >= F) {
-      unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        // unconditional: an idle lane (zero word) clears slot 0, which is zero at the end of a query either way
-        if (WIDE) {
-          smem_raw[w0.pc[u].x >> 15] = 0;
-          smem_raw[w0.pc[u].y >> 15] = 0;
-        } else if (SLOT2 && ACC8) {
-          smem_raw[w0.pc[u].x & 0xffffu] = 0;
-          smem_raw[w0.pc[u].y & 0xffffu] = 0;
-        } else if (SLOT2) {
-          *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].x & 0xffffu)) = 0;
-          *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].y & 0xffffu)) = 0;
         } else {
-          acc16w[w0.pc[u].x & 0xffffu] = 0;
-          acc16w[w0.pc[u].y & 0xffffu] = 0;
+          const uint32_t n_long = min(flags >> 1, (uint32_t)LONGCAP);
+          for (uint32_t j = 0; j < n_long; ++j) {  // long segments: swept by all adding waves, two postings per lane and pass
+            const uint2 sgm = longs[r0 * LONGCAP + j];
+            const float wq_ = cxs * long_w[r0 * LONGCAP + j];
+            for (uint32_t k = 2u * (uint32_t)atid; k < sgm.y; k += 2u * (uint32_t)ABLOCK) {
+              const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
+              visit(a0.x, wq_);
+              if (k + 1u < sgm.y) visit(a0.y, wq_);
+            }
+          }
         }
       }
-    }
-    if (tid == 0) facts[r0] = make_uint2(0u, 0u);  // (read one round ago; staged again in the next round)
-    __syncthreads();  // cleared: the next query starts from zero
+      __syncthreads();  // every add of the round has landed
 
-    R4 = R5;
-  };
-  int r0 = 0;
-  for (int v = v0; v < v1; v += 2) {
-    round(wfa, wfb, v, r0);
-    r0 = r0 == 2 ? 0 : r0 + 1;
-    if (v + 1 >= v1) break;
-    round(wfb, wfa, v + 1, r0);
-    r0 = r0 == 2 ? 0 : r0 + 1;
+      if (rare) {  // (long or direct sweeps, or chunks past the window: their postings are not in registers) whole-tile clear
+        for (int i = atid * 4; i < cb / APW; i += ABLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          // unconditional: an idle lane (zero word) clears slot 0, which is zero at the end of a query either way
+          if (WIDE) {
+            smem_raw[w0.pc[u].x >> 15] = 0;
+            smem_raw[w0.pc[u].y >> 15] = 0;
+          } else if (SLOT2 && ACC8) {
+            smem_raw[w0.pc[u].x & 0xffffu] = 0;
+            smem_raw[w0.pc[u].y & 0xffffu] = 0;
+          } else if (SLOT2) {
+            *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].x & 0xffffu)) = 0;
+            *reinterpret_cast<unsigned short *>(smem_raw + (w0.pc[u].y & 0xffffu)) = 0;
+          } else {
+            acc16w[w0.pc[u].x & 0xffffu] = 0;
+            acc16w[w0.pc[u].y & 0xffffu] = 0;
+          }
+        }
+      }
+      __syncthreads();  // cleared: the next query starts from zero
+    };
+    int r0 = 0;
+    for (int v = v0; v < v1; v += 2) {
+      round(wfa, wfb, v, r0);
+      r0 = r0 == 2 ? 0 : r0 + 1;
+      if (v + 1 >= v1) break;
+      round(wfb, wfa, v + 1, r0);
+      r0 = r0 == 2 ? 0 : r0 + 1;
+    }
   }
   __syncthreads();
   if (tid < 3) stat[tid] = 0;
