@@ -44,7 +44,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   constexpr uint32_t ABITS = ACC8 ? 8u : 16u;
   constexpr bool WIDE = ACC8 && BLOCK > 512;
   constexpr int CH = 16, LPC = CH / 2, GPW = kWave / LPC, WIN = GPW * U;
-  constexpr int SLOTS = 2 * WIN < 48 ? 2 * WIN : 48;  // strip slots per wave and round (>= WIN)
+  constexpr int SLOTS = 2 * WIN < 48 ? 2 * WIN : (WIN > 48 ? WIN : 48);  // strip slots per wave and round (>= WIN)
   static_assert(SLOTS >= WIN, "the register window reads the first WIN slots of a strip");
   constexpr int kLongLen = kLongLenW;
   constexpr int CBMAX = WIDE ? 131072 : (BLOCK <= 512 && !ACC8 ? 32768 : 65536);

@@ -50,6 +50,7 @@ struct DebugCfg {
   bool no_acc8 = false;        // no_acc8        term shards keep 16-bit accumulators over 32768-row tiles
   int flat_group = -1;         // flat_group=L   k_probe_even: 2^L staging lanes per term (default: as many as keep the staging waves <= 1/4)
   int pad_lds = 0;             // pad_lds=N      N bytes of dynamic LDS on the filter launch (occupancy experiments)
+  bool even_wide = false;      // even_wide      k_probe_even also with one staging lane per term and windows of up to 7 steps (experiment)
   bool no_even = false;        // no_even        the filter stages every round on all waves (k_probe_coarse), never on F of them (k_probe_even)
   int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
   bool bank_order = false;     // bank_order     experiment: bank-aware posting order inside short segments (k_seg_bank_order)
@@ -83,6 +84,7 @@ DebugCfg parse_debug_env() {
     else if (key == "no_tail") d.no_tail = val != 0;
     else if (key == "no_acc8") d.no_acc8 = val != 0;
     else if (key == "no_even") d.no_even = val != 0;
+    else if (key == "even_wide") d.even_wide = val != 0;
     else if (key == "pad_lds") d.pad_lds = (int)val;
     else if (key == "flat_group") d.flat_group = (int)val;
     else if (key == "seg_align") d.seg_align = val;
@@ -740,19 +742,30 @@ struct CxVariant {
 
 // k_probe_even's instantiations: (threads, window steps, shard rule, signed weights, 8-bit accumulators)
 #define APSS_EVEN_VARIANTS(X)          \
+  X(512, 7, false, false, false)       \
+  X(512, 6, false, false, false)       \
+  X(512, 5, false, false, false)       \
   X(512, 4, false, false, false)       \
   X(512, 3, false, false, false)       \
   X(512, 2, false, false, false)       \
+  X(512, 7, true, false, false)        \
+  X(512, 6, true, false, false)        \
+  X(512, 5, true, false, false)        \
   X(512, 4, true, false, false)        \
   X(512, 3, true, false, false)        \
   X(512, 2, true, false, false)        \
+  X(512, 7, true, false, true)         \
+  X(512, 6, true, false, true)         \
+  X(512, 5, true, false, true)         \
   X(512, 4, true, false, true)         \
   X(512, 3, true, false, true)         \
   X(512, 2, true, false, true)         \
   X(512, 4, false, false, true)        \
   X(512, 3, false, false, true)        \
   X(512, 2, false, false, true)        \
+  X(1024, 5, false, false, false)      \
   X(1024, 3, false, false, false)      \
+  X(1024, 5, false, false, true)       \
   X(1024, 3, false, false, true)
 
 bool cx_variant_exists(const CxVariant &v) {
@@ -1061,9 +1074,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     while (flat_group_log2 > 0 && ceil_div(q_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
     if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
     const int64_t flat_waves = std::max<int64_t>(1, ceil_div(q_max_nnz, kWave >> flat_group_log2));
-    // (measured, C3: T = 8 shards 32.1 vs 40.5 ms, T = 4 57.1 vs 62.4; with one lane per term -- T = 2, 75-term rows; C5's
-    // 200-term rows -- the staging waves' serial work outweighs what the others save: 80.6 vs 77 ms, 343 vs 331 ms)
-    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_group_log2 >= 1 &&
+    // where it is taken (measured on C3 and its shards, ms of the filter kernel, k_probe_even vs k_probe_coarse): term shards
+    // T = 8: 23.4 vs 40.5, T = 4: 48.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 69.7 vs 77.9; the plain
+    // handle of C3 itself (100-term rows, LDS-throughput-bound): 115.4 vs 111.3 -- so plain handles take it for thin rounds
+    // only (several staging lanes per term, windows of <= 4 steps), shard handles whenever the round fits
+    const bool wide_ok = shard_rule || dbg.even_wide;
+    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_group_log2 >= (wide_ok ? 0 : 1) &&
         flat_waves <= (int64_t)nw / 4) {
       CxVariant ev = cxv;
       ev.even = true;
@@ -1072,8 +1088,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       const double round_chunks = q_terms * cpt + 3.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
       int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
       // (a window that overflows most rounds pays a whole-tile clear each time; thin rounds only: windows of <= 4 steps)
-      const bool fits = ue <= (cxv.block == 1024 ? 3 : 4) && !cxv.sgn;
-      ue = cxv.block == 1024 ? 3 : std::max(2, ue);
+      const bool fits = ue <= (cxv.block == 1024 ? (dbg.even_wide ? 5 : 3) : (wide_ok ? 7 : 4)) && !cxv.sgn;
+      ue = cxv.block == 1024 ? (ue <= 3 ? 3 : 5) : std::max(2, ue);
       ev.u = ue;
       if (fits && cx_variant_exists(ev)) {
         cxv = ev;
