@@ -763,8 +763,12 @@ struct CxVariant {
   X(512, 4, false, false, true)        \
   X(512, 3, false, false, true)        \
   X(512, 2, false, false, true)        \
+  X(1024, 7, false, false, false)      \
+  X(1024, 6, false, false, false)      \
   X(1024, 5, false, false, false)      \
   X(1024, 3, false, false, false)      \
+  X(1024, 7, false, false, true)       \
+  X(1024, 6, false, false, true)       \
   X(1024, 5, false, false, true)       \
   X(1024, 3, false, false, true)
 
@@ -1078,7 +1082,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     // T = 8: 23.4 vs 40.5, T = 4: 48.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 69.7 vs 77.9; the plain
     // handle of C3 itself (100-term rows, LDS-throughput-bound): 115.4 vs 111.3 -- so plain handles take it for thin rounds
     // only (several staging lanes per term, windows of <= 4 steps), shard handles whenever the round fits
-    const bool wide_ok = shard_rule || dbg.even_wide;
+    // (the sparse regime's 1024-thread kernel, C5's shape at a fifth of N: 244.5 vs 291.5)
+    const bool wide_ok = shard_rule || cxv.block == 1024 || dbg.even_wide;
     if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_group_log2 >= (wide_ok ? 0 : 1) &&
         flat_waves <= (int64_t)nw / 4) {
       CxVariant ev = cxv;
@@ -1088,8 +1093,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       const double round_chunks = q_terms * cpt + 3.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
       int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
       // (a window that overflows most rounds pays a whole-tile clear each time; thin rounds only: windows of <= 4 steps)
-      const bool fits = ue <= (cxv.block == 1024 ? (dbg.even_wide ? 5 : 3) : (wide_ok ? 7 : 4)) && !cxv.sgn;
-      ue = cxv.block == 1024 ? (ue <= 3 ? 3 : 5) : std::max(2, ue);
+      const bool fits = ue <= (wide_ok ? 7 : 4) && !cxv.sgn;
+      ue = cxv.block == 1024 ? (ue <= 3 ? 3 : std::max(5, ue)) : std::max(2, ue);
       ev.u = ue;
       if (fits && cx_variant_exists(ev)) {
         cxv = ev;

@@ -50,7 +50,9 @@ def main(workloads):
             for k, v in pmc(src, d).items():
                 counters.setdefault(k, {}).update(v)
         out = {"workload": bench["config"]["workload"], "kernels": {}}
-        for pat, label in (("k_probe_coarse", "filter"), ("k_probe_wave", "exact"), ("k_head_gemm", "head")):
+        for pat, label in (("k_probe_even", "filter"), ("k_probe_coarse", "filter"), ("k_probe_wave", "exact"), ("k_head_gemm", "head")):
+            if label in out["kernels"]:
+                continue  # (the thin-round kernel when the launch took it, else the all-wave staging kernel)
             kr = [r for r in rows if pat in r["Name"]]
             c = pick(counters, pat)
             if not kr or not c:
