@@ -50,6 +50,7 @@ struct DebugCfg {
   bool no_acc8 = false;        // no_acc8        term shards keep 16-bit accumulators over 32768-row tiles
   int flat_group = -1;         // flat_group=L   k_probe_even: 2^L staging lanes per term (default: as many as keep the staging waves <= 1/4)
   int pad_lds = 0;             // pad_lds=N      N bytes of dynamic LDS on the filter launch (occupancy experiments)
+  bool longpf = false;         // longpf         prefetched, group-parallel long-segment sweeps on a plain handle too (experiment)
   bool even_wide = false;      // even_wide      k_probe_even also with one staging lane per term and windows of up to 7 steps (experiment)
   bool no_even = false;        // no_even        the filter stages every round on all waves (k_probe_coarse), never on F of them (k_probe_even)
   int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
@@ -85,6 +86,7 @@ DebugCfg parse_debug_env() {
     else if (key == "no_acc8") d.no_acc8 = val != 0;
     else if (key == "no_even") d.no_even = val != 0;
     else if (key == "even_wide") d.even_wide = val != 0;
+    else if (key == "longpf") d.longpf = val != 0;
     else if (key == "pad_lds") d.pad_lds = (int)val;
     else if (key == "flat_group") d.flat_group = (int)val;
     else if (key == "seg_align") d.seg_align = val;
@@ -145,6 +147,7 @@ struct apss_handle {
   DevBuf<float> q_val, q_sub;
   // ingest scratch
   DevBuf<int64_t> s_keep, s_cnt, s_rowdst, s_nnzdst, in_rowptr, in_ext;
+  DevBuf<int64_t> scan_tmp;  // block sums of a multi-block scan and their scan
   DevBuf<int32_t> in_idx;
   DevBuf<float> s_inv, s_sub, in_val;
   DevBuf<double> in_val64;
@@ -244,6 +247,23 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- ingest: validate (+ optional normalise / admission / value prune / term-range filter) and append ----
 // Source arrays are device pointers (batch-relative rowptr).  Destination: the store (to_store) or the query
 // staging buffers.  *n_out / *nnz_out: rows / entries that survived.
+// exclusive scan of n int64 (n + 1 outputs, out[n] = total) on the handle's stream
+int32_t scan_i64(apss_handle *h, const int64_t *in, int64_t *out, int64_t n) {
+  if (n <= 4 * kScanBlock) {
+    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, in, out, n);
+    HIPCHK(h, hipGetLastError());
+    return APSS_OK;
+  }
+  const int64_t nb = ceil_div(n, kScanBlock);
+  APSS_TRY(ensure(h, h->scan_tmp, (size_t)(2 * nb + 1)));
+  int64_t *sums = h->scan_tmp.p, *offs = h->scan_tmp.p + nb;
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(1024), 0, h->stream, in, sums, n);
+  hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)sums, offs, nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(1024), 0, h->stream, in, (const int64_t *)offs, out, n, nb);
+  HIPCHK(h, hipGetLastError());
+  return APSS_OK;
+}
+
 int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_idx,
                const float *d_val, const int64_t *d_ext, bool to_store, int64_t *n_out, int64_t *nnz_out) {
   *n_out = 0;
@@ -287,8 +307,8 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   if (transform) {
     APSS_TRY(ensure(h, h->s_rowdst, (size_t)n + 1));
     APSS_TRY(ensure(h, h->s_nnzdst, (size_t)n + 1));
-    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->s_keep.p, h->s_rowdst.p, n);
-    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->s_cnt.p, h->s_nnzdst.p, n);
+    APSS_TRY(scan_i64(h, (const int64_t *)h->s_keep.p, h->s_rowdst.p, n));
+    APSS_TRY(scan_i64(h, (const int64_t *)h->s_cnt.p, h->s_nnzdst.p, n));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(&kept_rows, h->s_rowdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&kept_nnz, h->s_nnzdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -716,6 +736,7 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
   X(512, 3, false, 16, false, false, false, true)    \
   X(512, 2, false, 16, false, false, false, true)    \
   X(512, 5, true, 16, false, false, true, false)     \
+  X(512, 5, false, 16, false, false, true, false)    \
   X(512, 5, true, 16, true, false, true, false)      \
   X(512, 4, false, 8, false, false, false, false)    \
   X(512, 5, false, 16, true, false, false, false)    \
@@ -1070,6 +1091,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       u = 5;
       cxv.longpf = true;
     }
+    if (dbg.longpf && cxv.block == 512 && !cxv.vrows && !cxv.sgn && !cxv.acc8) {
+      u = 5;
+      cxv.longpf = true;
+    }
     cxv.u = u;
     // k_probe_even (apss_even.hpp): the round staged by F waves, its chunks dealt out evenly -- a wave's window then holds a
     // 1/NW share of the ROUND's chunks (mean + 3 sigma over rounds), not the chunks of the wave's own terms
@@ -1136,7 +1161,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     APSS_TRY(ensure(h, h->vrow_first, (size_t)nq + 2));
     APSS_TRY(ensure(h, h->vq_first, (size_t)nq + 1));
     hipLaunchKernelGGL(k_vrow_count, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, h->stream, q_rowptr, nq, vrow_part, h->vrow_np.p);
-    hipLaunchKernelGGL(k_scan_i64, dim3(1), dim3(1024), 0, h->stream, (const int64_t *)h->vrow_np.p, h->vrow_first.p, nq);
+    APSS_TRY(scan_i64(h, (const int64_t *)h->vrow_np.p, h->vrow_first.p, nq));
     HIPCHK(h, hipGetLastError());
     int64_t nv = 0;
     HIPCHK(h, hipMemcpyAsync(&nv, h->vrow_first.p + nq, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
@@ -1581,7 +1606,7 @@ void apss_destroy(apss_handle *h) {
   for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); }
   release(h->tile_min); release(h->tile_min_c); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
-  release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst);
+  release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst); release(h->scan_tmp);
   release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val); release(h->in_val64); release(h->vq_first); release(h->vrow_q); release(h->vrow_ptr); release(h->vrow_np); release(h->vrow_first);
   release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword); release(h->dbg);
   release(h->head_pos); release(h->idx_tail); release(h->W); release(h->q_W); release(h->df); release(h->dedup_tab);

@@ -241,6 +241,63 @@ __global__ __launch_bounds__(1024) void k_scan_i64(const int64_t *in, int64_t *o
   if (tid == 1023) out[n] = part[1023];
 }
 
+// the same scan for large n, three launches: k_scan_sums (one sum per block of kScanBlock elements), k_scan_i64 over the
+// block sums, k_scan_apply (block-local exclusive scan + the block's offset).  The single-workgroup kernel alone walked a
+// million elements with one strided stream per thread: 3.6 ms per call, two calls per ingest of a term shard (7 of the
+// 33 ms of a T = 8 shard's step).
+constexpr int kScanBlock = 4096;  // elements per 1024-thread block, 4 consecutive per thread
+__device__ __forceinline__ int64_t block_excl_scan_1024(int64_t v, int64_t *wave_tot /*[17] LDS*/, int64_t *total) {
+  const int tid = threadIdx.x, ln = tid % kWave, wv = tid / kWave;
+  int64_t x = v;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int64_t y = __shfl_up(x, o);
+    if (ln >= o) x += y;
+  }
+  if (ln == kWave - 1) wave_tot[wv] = x;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t run = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int64_t t = wave_tot[w];
+      wave_tot[w] = run;
+      run += t;
+    }
+    wave_tot[16] = run;
+  }
+  __syncthreads();
+  *total = wave_tot[16];
+  return wave_tot[wv] + x - v;
+}
+__global__ __launch_bounds__(1024) void k_scan_sums(const int64_t *in, int64_t *sums, int64_t n) {
+  __shared__ int64_t wave_tot[17];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * 4;
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s += base + k < n ? in[base + k] : 0;
+  int64_t total;
+  (void)block_excl_scan_1024(s, wave_tot, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(const int64_t *in, const int64_t *block_off, int64_t *out, int64_t n, int64_t n_blocks) {
+  __shared__ int64_t wave_tot[17];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * 4;
+  int64_t v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = base + k < n ? in[base + k] : 0;
+    s += v[k];
+  }
+  int64_t total;
+  int64_t run = block_off[blockIdx.x] + block_excl_scan_1024(s, wave_tot, &total);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_off[n_blocks];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // index build (IWA:61-71): for rows [row0, row1) of the store, fill the posting lists of their tiles.
 // tile_seg[T][t] = {first posting, length} of term t in tile T, relative to the tile's posting base.  Every
