@@ -1,36 +1,40 @@
 // k_probe_even: the FILTER pass of the two-pass join (k_probe_coarse's arithmetic and accumulators) restructured for
 // THIN rounds -- a term shard (BASELINE.json configs[3]: a dozen terms per query and shard) or a sparse regime -- where a
-// round carries a few hundred postings and its duration is a chain of latencies, not a throughput.
+// round carries a few hundred postings and its duration is a chain of serially issued instructions and latencies, not a
+// throughput.  DESIGN.md 5a has the measurements behind every choice below.
 //
 // What k_probe_coarse pays per round whatever the round holds: every wave stages its own share of the query's terms
-// (term k -> wave k % NW: descriptor loads, a wave-wide scan, strip writes: ~55 VALU instructions for two live lanes),
-// then adds, then -- after the first barrier -- an LDS read of the round's counters (survivors, overflow flag, long
-// list), the report loop, the clears and the second barrier: four dependent LDS round trips and two barriers, with two
-// workgroups per CU to hide them.  The T = 8 shard kernel measured 3,340 cycles per round (profiles/r02_summary.md).
+// (term k -> wave k % NW: descriptor loads, a wave-wide scan, strip writes for two live lanes), then adds, then -- after
+// the first barrier -- an LDS read of the round's counters (survivors, overflow flag, long list), the report loop, the
+// clears and the second barrier.  The T = 8 shard kernel measured 3,340 cycles per round (VALU and LDS half idle).
 //
 // Here:
-//  * STAGING BY F WAVES.  The terms of round t go to waves (t + i) % NW, i < F (F = ceil(longest query / 64), lane =
-//    term), which scan them once, two rounds ahead, and deal the chunks out EVENLY over the A = NW - F waves that add in
-//    round t: chunk j -> adding wave j % A, strip slot j / A.  A wave that stages in a round adds nothing in it, so the
-//    staging is off the adding waves' path to the barrier; the others skip it altogether.
+//  * FIXED ROLES.  Waves 0 .. F-1 STAGE every round and never add; waves F .. NW-1 ADD every round and never stage;
+//    each kind runs its own loop with the same two barriers per round.  F = ceil(longest query / (64 / G)), G = 1, 2 or 4
+//    staging lanes per term.  A staging wave scans the round's chunk counts once, two rounds ahead, and deals the chunks
+//    out EVENLY over the A = NW - F adding waves: chunk j -> adding wave j % A, strip slot j / A.
 //  * NOTHING IS READ AFTER THE FIRST BARRIER.  Everything a round needs to know about itself is a fact of its staging
-//    (chunks per wave, long segments, whether the window overflows -> whole-tile clear): it is read one round ahead, in
-//    the same LDS round trip as the next strip and the current adds.  A crossing is reported by the wave that sees it
-//    (ballot-compacted append to the global list), not through an LDS list that every wave re-reads after the barrier.
-//    So a round is: strip read + adds (one LDS round trip) -> tests, next loads -> barrier -> clears -> barrier.
+//    (chunks per wave, long segments, whether the window overflows -> whole-tile clear): an adding wave reads it one round
+//    ahead, in the same LDS round trip as its next strip and the current adds.  A crossing is reported by the wave that
+//    sees it (ballot-compacted append to the global list), not through an LDS list that every wave re-reads.
+//    So an adding wave's round is: strip read + adds (one LDS round trip) -> next loads, tests -> barrier -> clears -> barrier.
+//  * NO TRIPS THROUGH THE SCALAR UNIT ON THE HOT PATH.  Idle lanes add to spare LDS words / write spare strip entries
+//    (selects on the address, no exec masks); first touches and crossings are counted per lane; one branch per round takes
+//    everything unusual.  Loaded values are used a round after their load, by the next stage.
 //
 // Pipeline (round v of a workgroup = one query against the tile's accumulators):
-//   round v - 4 : staging waves of v load the query's terms            (load_I)
-//   round v - 3 :                  load the (tile, term) descriptors   (load_P)
-//   round v - 2 :                  scan + write chunk descriptors into strips[v % 3], long segments into longs[v % 3]
+//   round v - 5 : staging waves load the row's extent                  (load_R)
+//   round v - 4 :               load the query's terms                 (load_I)
+//   round v - 3 :               load the (tile, term) descriptors      (load_P)
+//   round v - 2 :               scan + write chunk descriptors into strips[v % 3], long segments into longs[v % 3]
 //   round v - 1 : every adding wave reads its strip and the round's facts, starts its posting loads
 //   round v     : adds + crossing tests (register window; chunks past the window straight from the strip), clear
 // The two workgroup barriers of round v - 2 separate the strip writes from their readers; the ring of three keeps the
 // strip of round v readable during round v while round v + 2 is being staged.
 //
 // A round whose chunks exceed the strips (A x SLOTS) or whose long segments exceed LONGCAP is flagged at staging and
-// swept by every wave straight from the index (one term per wave at a time): slow, unbounded, never wrong.
-// Queries of more than 64 x NW / 2 terms are not served (they stay with k_probe_coarse).
+// swept by the adding waves straight from the index (one term per wave at a time): slow, unbounded, never wrong.
+// Queries of more than 64 x NW / 4 terms are not served (they stay with k_probe_coarse; apss_hip.hip chooses).
 #pragma once
 #include "apss_kernels.hpp"
 
@@ -38,8 +42,12 @@ namespace apss {
 
 template <int BLOCK, int U, int LONGCAP, bool SHARD, bool SIGNED, bool ACC8>
 __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_even(const ProbeArgs a) {
+  // (Tried for C3's full rounds: workgroups of TEN waves -- the eight adding waves of the 512-thread kernel plus two staging
+  // waves, 87 VGPRs at five steps.  143 vs 111 ms: ten waves spread 3/3/2/2 over the SIMDs and the second workgroup of a CU
+  // needs a SIMD to hold six of them, i.e. <= 80 VGPRs; it did not become resident.)
   constexpr int NW = BLOCK / kWave;
   static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+  constexpr int NS = NW - 1;  // strips per ring slot: one per adding wave (at least one wave stages)
   constexpr bool SLOT2 = BLOCK <= 512;
   constexpr uint32_t ABITS = ACC8 ? 8u : 16u;
   constexpr bool WIDE = ACC8 && BLOCK > 512;
@@ -50,7 +58,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   constexpr int CBMAX = WIDE ? 131072 : (BLOCK <= 512 && !ACC8 ? 32768 : 65536);
   constexpr int APW = 32 / (int)ABITS;
   __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / APW + kWave];  // (+ one spare word per lane: idle lanes add there)
-  __shared__ uint2 strips[3 * NW * SLOTS + kWave];  // [3][NW][SLOTS] {byte offset of the chunk's first posting, weight bits} (+ one spare entry per lane)
+  __shared__ uint2 strips[3 * NS * SLOTS + kWave];  // [3][NS][SLOTS] {byte offset of the chunk's first posting, weight bits} (+ one spare entry per lane)
   __shared__ uint2 longs[3 * LONGCAP];
   __shared__ float long_w[3 * LONGCAP];
   __shared__ uint2 facts[4];  // per ring slot: {chunks of the round, bit 0: flagged for the direct sweep, bits 1..: long segments}
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // index through a DPP move, and every lane writes at most two descriptors -- to the strip, or to its own spare entry when
   // it has none (a select on the address, not an exec mask).  Everything unusual -- a long segment, a term of more than
   // 2 G chunks, a round that does not fit -- takes one branch.
-  uint2 *const spare_item = strips + 3 * NW * SLOTS + ln;
+  uint2 *const spare_item = strips + 3 * NS * SLOTS + ln;
   auto flatten = [&](const Seg &g, const int ring) {
     uint32_t len = g.len;
     my_visits += sub == 0u ? len : 0u;
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     if (LOGG == 2) j0 = (uint32_t)__builtin_amdgcn_update_dpp((int)j0, (int)j0, 0x00, 0xf, 0xf, false);       // quad_perm [0,0,0,0]
     else if (LOGG == 1) j0 = (uint32_t)__builtin_amdgcn_update_dpp((int)j0, (int)j0, 0xa0, 0xf, 0xf, false);  // quad_perm [0,0,2,2]
     const uint32_t wbits = __float_as_uint(cxs * g.w);
-    uint2 *const st = strips + ring * (NW * SLOTS);
+    uint2 *const st = strips + ring * (NS * SLOTS);
     auto put = [&](const uint32_t k) {
       // chunk j of the round -> adding wave j % A, slot j / A ((j + 0.5) / A is at least 1 / 2A away from an integer:
       // the float quotient truncates exactly for j < 2^16)
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   struct StripRead { uint2 fc; uint2 it[U]; };
   auto strip_read = [&](StripRead &sr, const int ring, const int rank) {
     sr.fc = facts[ring];
-    const uint2 *const st = strips + (ring * NW + rank) * SLOTS;
+    const uint2 *const st = strips + (ring * NS + rank) * SLOTS;
 #pragma unroll
     for (int u = 0; u < U; ++u) sr.it[u] = st[u * GPW + ln / LPC];
   };
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0.flags);
         const int mc = (int)(w0.info & ~kRare);
         if (mc > WIN) {  // chunks past the register window: straight from this wave's strip
-          const uint2 *const st = strips + (r0 * NW + rank) * SLOTS;
+          const uint2 *const st = strips + (r0 * NS + rank) * SLOTS;
           for (int c0 = WIN; c0 < mc; c0 += GPW) {
             const int c = c0 + ln / LPC;
             const uint2 it = st[min(c, SLOTS - 1)];

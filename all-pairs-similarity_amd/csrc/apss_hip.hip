@@ -1104,23 +1104,27 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
     const int64_t flat_waves = std::max<int64_t>(1, ceil_div(q_max_nnz, kWave >> flat_group_log2));
     // where it is taken (measured on C3 and its shards, ms of the filter kernel, k_probe_even vs k_probe_coarse): term shards
-    // T = 8: 23.4 vs 40.5, T = 4: 48.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 69.7 vs 77.9; the plain
-    // handle of C3 itself (100-term rows, LDS-throughput-bound): 115.4 vs 111.3 -- so plain handles take it for thin rounds
-    // only (several staging lanes per term, windows of <= 4 steps), shard handles whenever the round fits
-    // (the sparse regime's 1024-thread kernel, C5's shape at a fifth of N: 244.5 vs 291.5)
+    // T = 8: 23.4 vs 40.5, T = 4: 48.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 69.7 vs 77.9; the sparse
+    // regime's 1024-thread kernel (C5's shape at a fifth of N): 244.5 vs 291.5; the plain handle of C3 itself (100-term rows,
+    // LDS-throughput-bound): 101.7 vs 111.3 with six adding waves x 6 steps, 115.4 with 7 steps -- a plain 512-thread handle
+    // takes it when its adding waves issue no more window steps per round than k_probe_coarse's eight would
     const bool wide_ok = shard_rule || cxv.block == 1024 || dbg.even_wide;
-    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_group_log2 >= (wide_ok ? 0 : 1) &&
-        flat_waves <= (int64_t)nw / 4) {
+    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4) {
       CxVariant ev = cxv;
       ev.even = true;
       const double add_waves = nw - (double)flat_waves;               // a wave that stages a round adds nothing in it
       const double cpt = std::max(1.0, seg / 16.0 + 0.5);           // chunks per term
-      const double round_chunks = q_terms * cpt + 3.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
+      double round_chunks = q_terms * cpt + 3.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
+      // (a plain handle's rows are whole rows: no binomial share of the terms; the longest row bounds the round)
+      if (!shard_rule) round_chunks = std::min(round_chunks, 1.05 * (double)q_max_nnz * cpt);
       int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
-      // (a window that overflows most rounds pays a whole-tile clear each time; thin rounds only: windows of <= 4 steps)
-      const bool fits = ue <= (wide_ok ? 7 : 4) && !cxv.sgn;
+      // (a window that overflows most rounds pays a whole-tile clear each time)
+      const bool fits = ue <= 7 && !cxv.sgn && (wide_ok || add_waves * std::max(2, ue) <= nw * (double)cxv.u);
       ue = cxv.block == 1024 ? (ue <= 3 ? 3 : std::max(5, ue)) : std::max(2, ue);
       ev.u = ue;
+      if (dbg.diag)
+        fprintf(stderr, "[apss diag] even? block %d u %d | F %lld G %d A %.0f chunks %.1f ue %d fits %d exists %d q_max %lld q_terms %.1f seg %.1f\n", cxv.block, cxv.u,
+                (long long)flat_waves, 1 << flat_group_log2, add_waves, round_chunks, ue, (int)fits, (int)cx_variant_exists(ev), (long long)q_max_nnz, q_terms, seg);
       if (fits && cx_variant_exists(ev)) {
         cxv = ev;
         a.flat_waves = (int32_t)flat_waves;
