@@ -167,7 +167,7 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
     filter_kernel = "k_probe_coarse (16-bit LDS accumulators, 4-B postings) + k_rescore" if st["filter_survivors"] or not visits \
         else "k_probe_wave / k_probe"
     if st.get("thin_launches"):
-        filter_kernel = "k_probe_even (thin rounds: staging by F waves, chunks dealt evenly; 4-B postings) + k_rescore"
+        filter_kernel = "k_probe_even (F staging waves, chunks dealt evenly over the adding waves; LDS accumulators, 4-B postings) + k_rescore"
     out = {
         "value": cands / sec_per_step,
         "ms_per_step": sec_per_step * 1e3,
