@@ -99,6 +99,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.post_c + pbase), 0, (int)((pend - pbase) * 4), 0x00020000);
   constexpr uint32_t kOob = 0xfffffff0u;
   constexpr uint32_t kRare = 0x80000000u;  // WaveWork::info: the round needs more than the register window (see strip_loads)
+  constexpr uint32_t kCountMask = 0xffffu;  // WaveWork::info bits 16..19: window steps that hold chunks of this wave
+  // SKIP: a wave skips the window steps behind its last chunk (adds, tests, clears).  A wave otherwise issues all U steps
+  // whether or not their slots hold postings, and the LDS pipeline pays for each; the windows of shards and of the sparse
+  // regime are sized for the upper end of a varying term count.  Measured: C5's shape 244.5 -> 218.5 ms; where nearly every
+  // step is needed the branches cost more than they save (C3, plain 512-thread handle: 101.1 -> 102.4 ms): not there.
+  constexpr bool SKIP = BLOCK > 512 || SHARD;
+  // (the 1024-thread kernel only ever skips its LAST step: with every step behind a branch C5's shape measured 245 vs 219 ms)
+  constexpr int kFirstSkippable = BLOCK > 512 ? U - 1 : 0;
 
   for (int i = tid * 4; i < cb / APW + kWave; i += BLOCK * 4) *reinterpret_cast<uint4 *>(acc + i) = make_uint4(0u, 0u, 0u, 0u);
   if (tid < 8) facts_w[tid] = 0;
@@ -217,7 +225,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     // chunks j < tot with j % A == rank: ceil((tot - rank) / A)
     const uint32_t mine = (int)tot > rank ? (uint32_t)(((float)((int)tot - rank + A - 1) + 0.5f) * rcpA) : 0u;
     const bool rare = sr.fc.y != 0u || tot > (uint32_t)(A * WIN);
-    f.info = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mine | (rare ? kRare : 0u)));
+    const uint32_t steps = min((mine + (uint32_t)GPW - 1u) / (uint32_t)GPW, (uint32_t)U);
+    f.info = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mine | (rare ? kRare : 0u) | (steps << 16)));
     f.flags = sr.fc.y;
 #pragma unroll
     for (int u = 0; u < U; ++u) asm volatile("" : "+v"(sr.it[u].x), "+v"(sr.it[u].y));
@@ -337,10 +346,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         const uint32_t sh = WIDE ? (pcw >> 12) & 24u : (SLOT2 ? (pcw << 3) & 31u : (pcw & 1u) << 4);
         return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw ? addr : spare)), p << sh);
       };
+      const int n_steps = SKIP ? (int)((w0.info >> 16) & 0xfu) : U;  // (scalar: a branch on it costs no trip from the VALU)
       auto issue_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
           const int u = u0 + j;
+          if (SKIP && u >= kFirstSkippable && u >= n_steps) break;  // (one forward exit: the steps behind this wave's last chunk)
           if (u < U) {
             p0[j] = prod(w0.pc[u].x, w0.wq[u]);
             p1[j] = prod(w0.pc[u].y, w0.wq[u]);
@@ -356,6 +367,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
           const int u = u0 + j;
+          if (SKIP && u >= kFirstSkippable && u >= n_steps) break;
           if (u < U) {
             o0[j] = w0.pc[u].x ? half_of(o0[j], w0.pc[u].x) : thr1 + 1u;
             o1[j] = w0.pc[u].y ? half_of(o1[j], w0.pc[u].y) : thr1 + 1u;
@@ -367,6 +379,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
 #pragma unroll
           for (int j = 0; j < BATCH; ++j) {
             const int u = u0 + j;
+            if (SKIP && u >= kFirstSkippable && u >= n_steps) break;
             if (u < U) {
               report(thr1 - o0[j] < p0[j], slot_of(w0.pc[u].x), o0[j] + p0[j]);
               report(thr1 - o1[j] < p1[j], slot_of(w0.pc[u].y), o1[j] + p1[j]);
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       const bool rare = (w0.info & kRare) != 0u;  // more than the register windows: one branch per round
       if (rare) {
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0.flags);
-        const int mc = (int)(w0.info & ~kRare);
+        const int mc = (int)(w0.info & kCountMask);
         if (mc > WIN) {  // chunks past the register window: straight from this wave's strip
           const uint2 *const st = strips + (r0 * NS + rank) * SLOTS;
           for (int c0 = WIN; c0 < mc; c0 += GPW) {
@@ -443,6 +456,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         unsigned short *acc16w = reinterpret_cast<unsigned short *>(acc);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+          if (SKIP && u >= kFirstSkippable && u >= n_steps) break;
           // unconditional: an idle lane (zero word) clears slot 0, which is zero at the end of a query either way
           if (WIDE) {
             smem_raw[w0.pc[u].x >> 15] = 0;

@@ -1113,8 +1113,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       CxVariant ev = cxv;
       ev.even = true;
       const double add_waves = nw - (double)flat_waves;               // a wave that stages a round adds nothing in it
-      const double cpt = std::max(1.0, seg / 16.0 + 0.5);           // chunks per term
-      double round_chunks = q_terms * cpt + 3.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
+      // postings per (tile, term) over the terms this handle indexes (a term shard: its range, not the whole dimension)
+      const double seg_here = seg * (double)h->cfg.dim / (double)std::max<int64_t>(1, (int64_t)h->cfg.term_hi - h->cfg.term_lo);
+      const double cpt = std::max(1.0, seg_here / 16.0 + 0.5);      // chunks per term
+      // (mean + 2 sigma of a binomial share of the terms: the rounds beyond read their last chunks from the strip and end
+      // with a whole-tile clear, ~2 % of them; at 3 sigma the T = 8 shard took a 3-step window: 24.8 vs 23.2 ms)
+      double round_chunks = q_terms * cpt + 2.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
       // (a plain handle's rows are whole rows: no binomial share of the terms; the longest row bounds the round)
       if (!shard_rule) round_chunks = std::min(round_chunks, 1.05 * (double)q_max_nnz * cpt);
       int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
