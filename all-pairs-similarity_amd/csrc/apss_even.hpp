@@ -319,21 +319,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         const float x = __builtin_fmaf(wqs, __half2float(__ushort_as_half((unsigned short)(WIDE ? pcw & 0x7fffu : pcw >> 16))), 1.0f);
         return SIGNED ? (uint32_t)max((int)x, 1) : (uint32_t)x;
       };
-      auto add16 = [&](const uint32_t pcw, const uint32_t p) -> uint32_t {
-        if (WIDE) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + ((pcw >> 15) & 0x1fffcu)), p << ((pcw >> 12) & 24u));
-        if (SLOT2) return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw & 0xfffcu)), p << ((pcw << 3) & 31u));
-        const uint32_t slot = pcw & 0xffffu;
-        return atomicAdd(&acc[slot >> 1], p << ((slot & 1u) << 4));
-      };
       auto half_of = [&](const uint32_t old_word, const uint32_t pcw) {
         if (WIDE) return __builtin_amdgcn_ubfe(old_word, (pcw >> 12) & 24u, 8u);
         return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, ABITS) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
-      };
-      auto visit = [&](const uint32_t pcw, const float wqs) {  // (sweeps: divergent control flow)
-        const uint32_t p = prod(pcw, wqs);
-        const uint32_t old16 = half_of(add16(pcw, p), pcw);
-        my_cands += old16 == 0u ? 1u : 0u;
-        if (thr1 - old16 < p) report_lane(slot_of(pcw), old16 + p);
       };
       constexpr int BATCH = 3;
       // An idle lane (zero word) adds into ITS OWN spare word behind the accumulators (a select on the address) instead of
@@ -345,6 +333,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         const uint32_t addr = WIDE ? (pcw >> 15) & 0x1fffcu : (SLOT2 ? pcw & 0xfffcu : ((pcw & 0xffffu) >> 1) * 4u);
         const uint32_t sh = WIDE ? (pcw >> 12) & 24u : (SLOT2 ? (pcw << 3) & 31u : (pcw & 1u) << 4);
         return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw ? addr : spare)), p << sh);
+      };
+      // two postings of a sweep the same way: no masks around the atomics, one (rare, divergent) branch for both crossings
+      auto visit2 = [&](const uint32_t x, const uint32_t y, const float wqs) {
+        const uint32_t px = prod(x, wqs), py = prod(y, wqs);
+        uint32_t ox = add_or_spare(x, px), oy = add_or_spare(y, py);
+        ox = x ? half_of(ox, x) : thr1 + 1u;
+        oy = y ? half_of(oy, y) : thr1 + 1u;
+        my_cands += (ox == 0u ? 1u : 0u) + (oy == 0u ? 1u : 0u);
+        if ((thr1 - ox < px) | (thr1 - oy < py)) {
+          if (thr1 - ox < px) report_lane(slot_of(x), ox + px);
+          if (thr1 - oy < py) report_lane(slot_of(y), oy + py);
+        }
       };
       const int n_steps = SKIP ? (int)((w0.info >> 16) & 0xfu) : U;  // (scalar: a branch on it costs no trip from the VALU)
       auto issue_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
@@ -414,8 +414,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
             const int c = c0 + ln / LPC;
             const uint2 it = st[min(c, SLOTS - 1)];
             const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, c < mc ? it.x + lo * 8u : kOob, 0, 0);
-            if (two.x) visit(two.x, __uint_as_float(it.y));
-            if (two.y) visit(two.y, __uint_as_float(it.y));
+            visit2(two.x, two.y, __uint_as_float(it.y));
           }
         }
         if (flags & 1u) {  // flagged at staging: every term straight from the index, one term per adding wave at a time
@@ -431,8 +430,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
             const apss_u32x2 sg = __builtin_amdgcn_raw_buffer_load_b64(rs_tp, term * 8u, 0, 0);
             for (uint32_t p = 2u * (uint32_t)ln; p < sg.y; p += 2u * kWave) {
               const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sg.x + p) * 4u, 0, 0);
-              if (two.x) visit(two.x, wq_);
-              if (two.y && p + 1u < sg.y) visit(two.y, wq_);
+              visit2(two.x, p + 1u < sg.y ? two.y : 0u, wq_);
             }
           }
         } else {
@@ -442,8 +440,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
             const float wq_ = cxs * long_w[r0 * LONGCAP + j];
             for (uint32_t k = 2u * (uint32_t)atid; k < sgm.y; k += 2u * (uint32_t)ABLOCK) {
               const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-              visit(a0.x, wq_);
-              if (k + 1u < sgm.y) visit(a0.y, wq_);
+              visit2(a0.x, k + 1u < sgm.y ? a0.y : 0u, wq_);
             }
           }
         }

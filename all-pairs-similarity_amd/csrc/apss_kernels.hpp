@@ -1634,6 +1634,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       const uint32_t sh = WIDE ? (pcw >> 12) & 24u : (SLOT2 ? (pcw << 3) & 31u : (pcw & 1u) << 4);
       return atomicAdd(reinterpret_cast<uint32_t *>(smem_raw + (pcw ? addr : spare)), p << sh);
     };
+    // two postings of a sweep the same way: no masks around the atomics, one (rare, divergent) branch for both crossings
+    auto visit2 = [&](const uint32_t x, const uint32_t y, const float wqs) {
+      const uint32_t px = prod(x, wqs), py = prod(y, wqs);
+      uint32_t ox = add_or_spare(x, px), oy = add_or_spare(y, py);
+      ox = x ? half_of(ox, x) : thr1 + 1u;
+      oy = y ? half_of(oy, y) : thr1 + 1u;
+      my_cands += (ox == 0u ? 1u : 0u) + (oy == 0u ? 1u : 0u);
+      if ((thr1 - ox < px) | (thr1 - oy < py)) {
+        crossed(slot_of(x), px, ox);
+        crossed(slot_of(y), py, oy);
+      }
+    };
     auto issue_batch = [&](const int u0, uint32_t (&p0)[BATCH], uint32_t (&p1)[BATCH], uint32_t (&o0)[BATCH], uint32_t (&o1)[BATCH]) {
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
@@ -1737,13 +1749,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
           const apss_u32x2 cur = n1;
           n1 = n2;
           n2 = first_pass(i + 2u);
-          if (cur.x) visit(cur.x, wq_);
-          if (cur.y) visit(cur.y, wq_);
+          visit2(cur.x, cur.y, wq_);
           if (mine)
             for (uint32_t k = 2u * gt + PASS; k < sgm.y; k += PASS) {  // further passes of a segment of > PASS postings
               const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-              if (a0.x) visit(a0.x, wq_);
-              if (a0.y) visit(a0.y, wq_);
+              visit2(a0.x, a0.y, wq_);
             }
         }
       }
@@ -1756,15 +1766,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         for (; k + 2u * BLOCK < sgm.y; k += 4u * BLOCK) {
           const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
           const apss_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k + 2u * BLOCK) * 4u, 0, 0);
-          visit(a0.x, wq_);
-          if (k + 1u < sgm.y) visit(a0.y, wq_);
-          visit(a1.x, wq_);
-          if (k + 2u * BLOCK + 1u < sgm.y) visit(a1.y, wq_);
+          visit2(a0.x, k + 1u < sgm.y ? a0.y : 0u, wq_);  // (a zero word is no posting: spare-word add, no mask)
+          visit2(a1.x, k + 2u * BLOCK + 1u < sgm.y ? a1.y : 0u, wq_);
         }
         for (; k < sgm.y; k += 2u * BLOCK) {
           const apss_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs_po, (sgm.x + k) * 4u, 0, 0);
-          visit(a0.x, wq_);
-          if (k + 1u < sgm.y) visit(a0.y, wq_);
+          visit2(a0.x, k + 1u < sgm.y ? a0.y : 0u, wq_);
         }
       }
     }
