@@ -242,6 +242,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // FIXED ROLES: waves 0 .. F-1 stage every round and never add, waves F .. NW-1 add every round and never stage.  The two
   // kinds run their own loops (same two barriers per round): no per-round role arithmetic on the scalar unit, and the
   // compiler allocates registers for one job at a time.
+  // (Tried: a staging wave taking TWO sets of terms per round -- half the staging waves, one more adding wave; C3 7 x 5
+  // window steps instead of 6 x 6.  The second set's registers tipped the kernel into scratch: 140 vs 101 ms.)
   const bool stager = wv < F;
   const int rank = wv - F;  // an adding wave's rank
   WaveWork wfa, wfb;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         if (WIDE) return __builtin_amdgcn_ubfe(old_word, (pcw >> 12) & 24u, 8u);
         return SLOT2 ? __builtin_amdgcn_ubfe(old_word, pcw << 3, ABITS) : (old_word >> ((pcw & 1u) << 4)) & 0xffffu;
       };
-      constexpr int BATCH = 3;
+      constexpr int BATCH = 3;  // (one batch of all six steps of C3's window: no change, 101.1 ms)
       // An idle lane (zero word) adds into ITS OWN spare word behind the accumulators (a select on the address) instead of
       // being masked off: an exec mask around each atomic is a trip VALU -> scalar unit -> VALU (compare, s_and_saveexec,
       // s_or) that cost ~64 cycles of the wave's serial issue per posting slot (profiles/microbench/issue_rate.hip).  Its
