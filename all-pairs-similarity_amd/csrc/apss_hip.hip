@@ -1096,18 +1096,18 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       cxv.longpf = true;
     }
     cxv.u = u;
-    // k_probe_even (apss_even.hpp): the round staged by F waves, its chunks dealt out evenly -- a wave's window then holds a
-    // 1/NW share of the ROUND's chunks (mean + 3 sigma over rounds), not the chunks of the wave's own terms
-    // staging lanes per term: as many as keep the staging waves at <= a quarter of the workgroup
+    // k_probe_even (apss_even.hpp): F waves stage the round, the others add an even share of its chunks -- a wave's window
+    // then holds a 1/A share of the ROUND's chunks, not the chunks of the wave's own terms.
+    // Staging lanes per term: as many as keep the staging waves at <= a quarter of the workgroup.
     int flat_group_log2 = 2;
     while (flat_group_log2 > 0 && ceil_div(q_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
     if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
     const int64_t flat_waves = std::max<int64_t>(1, ceil_div(q_max_nnz, kWave >> flat_group_log2));
-    // where it is taken (measured on C3 and its shards, ms of the filter kernel, k_probe_even vs k_probe_coarse): term shards
-    // T = 8: 23.4 vs 40.5, T = 4: 48.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 69.7 vs 77.9; the sparse
-    // regime's 1024-thread kernel (C5's shape at a fifth of N): 244.5 vs 291.5; the plain handle of C3 itself (100-term rows,
-    // LDS-throughput-bound): 101.7 vs 111.3 with six adding waves x 6 steps, 115.4 with 7 steps -- a plain 512-thread handle
-    // takes it when its adding waves issue no more window steps per round than k_probe_coarse's eight would
+    // Where it is taken (measured on C3 and its shards, ms of the filter kernel, k_probe_even vs k_probe_coarse): term shards
+    // T = 8: 23.4 vs 40.5, T = 4: 35.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 58.7 vs 77.9; the sparse
+    // regime's 1024-thread kernel (C5's shape at a fifth of N): 218.2 vs 291.5; the plain handle of C3 itself (100-term rows,
+    // LDS-throughput-bound): 100.6 vs 111.3 with six adding waves x 6 steps, 115.4 with 7 steps -- a plain 512-thread handle
+    // takes it when its adding waves issue no more window steps per round than k_probe_coarse's eight would.
     const bool wide_ok = shard_rule || cxv.block == 1024 || dbg.even_wide;
     if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4) {
       CxVariant ev = cxv;
