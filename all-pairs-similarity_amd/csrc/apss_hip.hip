@@ -741,6 +741,7 @@ int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
   X(512, 4, false, 8, false, false, false, false)    \
   X(512, 5, false, 16, true, false, false, false)    \
   X(512, 5, false, 16, false, true, false, false)    \
+  X(512, 5, true, 16, false, true, false, false)     \
   X(512, 5, false, 16, true, true, false, false)     \
   X(1024, 5, false, 16, false, false, false, false)  \
   X(1024, 3, false, 16, false, false, false, false)  \
@@ -964,10 +965,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // down per query and tile: the kernel clamps it at 1, which only admits more
   const bool hybrid_wanted = h->head_k > 0;
   const float head_thr = (float)(theta - 0.0080 * bound - 1e-5);
-  // weights of either sign with theta > 0 go through the filter too (it then sums positive products only); shard-rule
-  // launches (and long queries over 65536-row tiles) have no such instantiation and keep the general kernel
+  // weights of either sign with theta > 0 go through the filter too (it then sums positive products only: an upper bound of
+  // the partial score, under the shard rule as much as without it -- the rule's ratios are norms); a handle with a
+  // dense-head block (and long queries over 65536-row tiles) has no such instantiation and keeps the general kernel
   const bool shard_rule = h->sharded || hybrid_wanted;
-  const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !shard_rule &&
+  const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !hybrid_wanted &&
                          (h->cx.cb <= 32768 || q_max_nnz <= 512) && !dbg.chunk8 && !dbg.window;
   // 65536-row tiles (term shards; the sparse regime of a plain handle): the 8-bit filter -- 65536 candidates in 64 KB, two
   // 512-thread workgroups per CU -- if this call's norms and row lengths leave room for its sums

@@ -201,3 +201,38 @@ def test_8bit_shard_filter_falls_back_when_a_query_batch_does_not_fit(oracle):
     assert_same_pairs(got, want, theta, band=1e-4, tol=1e-4)
     for ix in shards:
         ix.close()
+
+
+def test_signed_weights_under_the_shard_rule(oracle):
+    """weights of either sign on term-range shards: the two-pass filter (positive products only, shard-rule normalisation)
+    instead of the general kernel; candidates + exact partial scores give the oracle's set"""
+    import torch
+    from apss.dist import HipShardEngine, join_shards_local, term_ranges
+    rng = np.random.default_rng(733)
+    n, dim, nnz, theta = 6000, 3000, 30, 0.6
+    rows = []
+    for i in range(n):
+        if i > 20 and rng.random() < 0.15:  # a noisy copy of an earlier row, a few signs flipped
+            t, v = rows[rng.integers(0, i)]
+            w = v * (1 + 0.02 * rng.standard_normal(v.size))
+            w[rng.random(v.size) < 0.05] *= -1
+            rows.append((t, w / np.linalg.norm(w)))
+            continue
+        t = np.sort(rng.choice(dim, size=nnz, replace=False)).astype(np.int32)
+        v = rng.standard_normal(nnz)
+        rows.append((t, v / np.linalg.norm(v)))
+    rp = np.arange(0, (n + 1) * nnz, nnz, dtype=np.int64)
+    idx = np.concatenate([t for t, _ in rows]).astype(np.int32)
+    val = np.concatenate([v for _, v in rows]).astype(np.float64)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 300
+    dev = torch.device("cuda", 0)
+    ranges = term_ranges(np.bincount(idx, minlength=dim), 3)
+    engines = [HipShardEngine(dim, theta, tr, dev) for tr in ranges]
+    for e in engines:
+        e.load(rp, idx, val)
+    q, c, s, _ = join_shards_local(engines, n, theta)
+    assert_same_pairs(to_map(q, c, s), want, theta)
+    # (a shard's survivors are its candidates; what shows the filter ran instead of the general kernel is its time:
+    # profiles/r02_summary.md, "signed weights under the shard rule")
+    assert sum(e.stats["posting_visits"] for e in engines) == int((np.bincount(idx, minlength=dim).astype(np.int64) ** 2).sum())
