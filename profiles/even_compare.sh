@@ -1,3 +1,6 @@
+#!/bin/bash
+# k_probe_even vs k_probe_coarse (APSS_DEBUG=no_even) on a T = 8 / T = 2 term shard of C3, on C3 itself and on C5's shape:
+# step time and result-set size of each (run on the GPU box from the repo root).
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/ev
 for dbg in "" "no_even"; do
   for g in 8,1,3,0 2,1,1,0 1,1,0,0; do
