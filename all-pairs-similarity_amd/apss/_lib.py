@@ -15,8 +15,9 @@ SYMBOLS = [
     "apss_create", "apss_destroy", "apss_last_error", "apss_set_stream", "apss_insert", "apss_query",
     "apss_insert_and_query", "apss_self_join", "apss_result_count", "apss_fetch_results", "apss_size",
     "apss_stats_get", "apss_insert_dev", "apss_query_dev", "apss_insert_and_query_dev", "apss_clear",
-    "apss_results_dev", "apss_results_copy_dev", "apss_partial_scores_dev",
+    "apss_results_dev", "apss_results_copy_dev", "apss_partial_scores_dev", "apss_set_head_terms", "apss_get_head_terms",
 ]
+DOWNGRADE_ACC8, DOWNGRADE_HEAD = 1, 2
 
 
 class Config(C.Structure):
@@ -32,13 +33,20 @@ class Stats(C.Structure):
                 ("build_ms", C.c_double), ("probe_launches", C.c_int64), ("hbm_bytes", C.c_int64),
                 ("filter_survivors", C.c_int64), ("rescore_ms", C.c_double),
                 ("head_terms", C.c_int64), ("head_pairs", C.c_int64), ("head_survivors", C.c_int64),
-                ("head_ms", C.c_double), ("head_flops", C.c_double), ("thin_launches", C.c_int64)]
+                ("head_ms", C.c_double), ("head_flops", C.c_double), ("thin_launches", C.c_int64),
+                ("downgrades", C.c_uint32), ("reserved0", C.c_uint32), ("probe_kernel", C.c_char * 64)]
+
+
+def build_sources():
+    """every file libapss_hip.so is compiled from: the translation unit, every header beside it, the ABI header"""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))) + [
+        os.path.normpath(os.path.join(CSRC, "..", "..", "include", "apss.h"))]
 
 
 def build(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  In-tree output, travels with gpurun."""
-    srcs = [os.path.join(CSRC, f) for f in ("apss_hip.hip", "apss_kernels.hpp", "apss_head.hpp")] + [
-        os.path.normpath(os.path.join(CSRC, "..", "..", "include", "apss.h"))]
+    srcs = build_sources()
     if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -125,5 +133,9 @@ def lib():
     L.apss_results_copy_dev.argtypes = [vp, i64, i64, vp, vp, vp]
     L.apss_partial_scores_dev.restype = i32
     L.apss_partial_scores_dev.argtypes = [vp, i64, vp, vp, vp]
+    L.apss_set_head_terms.restype = i32
+    L.apss_set_head_terms.argtypes = [vp, i32, vp, i32, i32]
+    L.apss_get_head_terms.restype = i32
+    L.apss_get_head_terms.argtypes = [vp, i32, vp, C.POINTER(i32)]
     _lib = L
     return L

@@ -18,6 +18,16 @@ A dense all-reduce of per-query accumulators would move 4*N bytes per query (SUR
 the single-GPU join); this exchange moves O(#near-pairs).  No precondition on the norms (the reference assumes
 normalised vectors, CommonUtils.scala:88; un-normalised input gives the same pairs as the single-GPU join).
 
+Skewed term distributions (TF-IDF is Zipfian; BASELINE.json configs[4]): the most frequent terms H are taken out of
+EVERY shard's term range and scored as a dense block on the matrix cores (csrc/apss_head.hpp).  The candidate rule's
+proof holds for any partition of the terms, so {H, T_1 .. T_T} is one: a pair with total >= theta passes
+p_g >= theta |q_g||c_g| / (|q||c|) for some g in {H, T_1, .., T_T}.  The tail tests run on the shards as before (the
+ratios exclude H); the head test  w_q . w_c >= theta  (w_x = x_H |x| / |x_H|, bf16 MFMA contraction) is cut over the T
+ranks of a group by CANDIDATE ROW -- rank i multiplies the 64-row candidate tiles t with t % T == i against the whole
+query batch -- and its survivors join the same candidate lists: all-gather, exact partial scores (a head term's entry
+stays in the store of the shard whose range holds it), all-reduce, threshold.  Every rank must use the same H: rank 0
+decides (the library's own policy on a sample of the rows) and broadcasts the terms once, at load time.
+
 The compute engine is injected so the host logic can be exercised on CPU with gloo in tests (tests/ provides an
 engine backed by the CPU oracle); the product engine below is HIP-only.
 """
@@ -41,14 +51,31 @@ def term_ranges(df, world):
     return [(cuts[g], cuts[g + 1]) for g in range(world)]
 
 
+def hip_head_chooser(dim, theta, device, head_terms=0, sample_rows=131072):
+    """The dense-head block of a sharded join, decided by the library's own policy (choose_head in csrc/apss_hip.hip:
+    sampled document frequencies, measured selectivity) on the first `sample_rows` rows of the batch: a plain handle
+    indexes the sample and is asked which terms it took.  head_terms: 0 = policy, 64 | 128 | 256 = that many."""
+    def choose(rp, idx, val):
+        from .engine import ApssIndex
+        m = int(min(len(rp) - 1, sample_rows))
+        e = int(rp[m])
+        with ApssIndex(dim, theta, device=device.index or 0, head_terms=head_terms) as ix:
+            ix.insert(np.arange(m, dtype=np.int64), rp[:m + 1], idx[:e], val[:e])
+            return ix.head_terms()
+    return choose
+
+
 class HipShardEngine:
     """One shard resident on one MI355X (libapss_hip.so through the C ABI; no fallback): the postings of the terms in
-    `term_range` for the candidate rows in `row_range`.  Queries are always all rows of the batch."""
+    `term_range` for the candidate rows in `row_range`.  Queries are always all rows of the batch.
+    head = (terms, part, n_parts): the join's dense-head block and this shard's share of its candidate tiles."""
 
-    def __init__(self, dim, theta, term_range, device, tile_rows=0):
+    def __init__(self, dim, theta, term_range, device, tile_rows=0, head=None):
         from .engine import ApssIndex
         self.device = device
         self.ix = ApssIndex(dim, theta, device=device.index or 0, tile_rows=tile_rows, term_range=term_range)
+        if head is not None and len(head[0]):
+            self.ix.set_head_terms(head[0], head[1], head[2])
         # run on torch's stream: the tensors handed to the library are produced by torch kernels on that stream
         self.ix.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
@@ -83,6 +110,8 @@ class HipShardEngine:
             self.ix.insert_dev(self.s_ids, self.s_rp, self.s_idx, self.s_val)
             n = self.ix.query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
         self.stats = self.ix.stats()
+        # query row == batch row and candidate slot == row - r0 only while ingest keeps every row (no admission filter here)
+        assert self.stats["rows"] == self.r1 - self.r0, "shard engine: the handle dropped rows"
         return n
 
     def candidates(self):
@@ -129,13 +158,16 @@ class ShardedJoin:
 
     T term shards share a candidate range and combine their partial scores with an all-reduce inside their group
     (the exchange the term-sharded index needs); the D candidate ranges are independent (their result sets are
-    disjoint).  Term shards do not speed this join up: a shard has 1/T of the posting visits of every (query, tile)
-    round but the same number of rounds, and a round's cost is mostly fixed (a T = 2 shard takes as long
-    as the whole join on one GPU) -- so the default is T = 1 (candidate ranges only, no data-path collective); `term_shards` selects
-    the term-sharded layouts with their RCCL exchange."""
+    disjoint).  A term shard has 1/T of the posting visits of every (query, tile) round but the same number of rounds,
+    so its speed-up trails T (measured one shard at a time, T = 8 is 4.2x one GPU before the exchange,
+    eight candidate ranges 6.0x); candidate ranges need no data-path collective.  `term_shards` = T picks the layout:
+    bench.py's headline is T = world (the layout BASELINE.json names), this class's default T = 1.
+    head_terms: dense-head block of the term-sharded layouts (module docstring): 0 = the library's policy decides on rank 0,
+    -1 = never, 64 | 128 | 256 = that many of the most frequent terms.  (With T = 1 every handle is a plain one and decides
+    for itself.)"""
 
     def __init__(self, dim, theta, rank, world, device, tile_rows=0, engine_factory=None, comm_device=None,
-                 term_shards=None):
+                 term_shards=None, head_terms=0, head_chooser=None):
         self.dim, self.theta, self.rank, self.world, self.device = dim, float(theta), rank, world, device
         # collectives run on `comm_device` tensors: the GPU itself under RCCL, the CPU when rehearsing with gloo
         self.comm = comm_device or device
@@ -151,17 +183,40 @@ class ShardedJoin:
                 g = dist.new_group([j * T + i for i in range(T)])
                 if j == self.dj:
                     self.group = g
-        self.engine_factory = engine_factory or (lambda tr: HipShardEngine(dim, theta, tr, device, tile_rows))
+        self.engine_factory = engine_factory or (lambda tr, head=None: HipShardEngine(dim, theta, tr, device, tile_rows, head))
+        self.head_mode = head_terms
+        self.head_chooser = head_chooser or hip_head_chooser(dim, theta, device, max(0, head_terms))
+        self.head = np.zeros(0, np.int32)
         self.last = {}
+
+    def _decide_head(self, rp, idx, val):
+        """rank 0 asks the policy, every rank gets the same terms (one broadcast at load time, not in the data path)"""
+        buf = torch.zeros(257, dtype=torch.int32, device=self.comm)
+        if self.rank == 0:
+            t = np.asarray(self.head_chooser(rp, idx, val), dtype=np.int32)[:256]
+            buf[0] = int(t.size)
+            if t.size:
+                buf[1:1 + t.size] = torch.from_numpy(t).to(self.comm)
+        if self.world > 1:
+            dist.broadcast(buf, src=0)
+        h = buf.cpu().numpy()
+        return h[1:1 + int(h[0])].astype(np.int32)
 
     def load(self, rp, idx, val):
         """every rank holds the same batch (same seed / same broadcast); each indexes only its terms x rows"""
         df = np.bincount(idx, minlength=self.dim)
+        if self.T > 1 and self.head_mode >= 0:
+            self.head = self._decide_head(rp, idx, val)
+            df = df.copy()
+            df[self.head] = 0  # the block's terms are in no shard's index: the ranges balance the tail's visits
         self.ranges = term_ranges(df, self.T)
         self.term_range = self.ranges[self.ti]
         self.n = len(rp) - 1
         self.row_range = (self.n * self.dj // self.D, self.n * (self.dj + 1) // self.D)
-        self.engine = self.engine_factory(self.term_range)
+        if self.head.size:
+            self.engine = self.engine_factory(self.term_range, head=(self.head, self.ti, self.T))
+        else:
+            self.engine = self.engine_factory(self.term_range)
         self.engine.load(rp, idx, val, None if self.D == 1 else self.row_range)
 
     def _all_gather_var(self, t):
@@ -188,6 +243,8 @@ class ShardedJoin:
                 dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             self.last = {
                 "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
+                "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
+                "head_terms": st.get("head_terms", 0),
                 "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
                 "exchange": {"term_shards": 1, "candidate_ranges": self.D, "candidates_per_rank": [int(n_mine)],
                              "union": int(n_mine), "all_gather_bytes_per_rank": 0, "all_reduce_bytes": 0,
@@ -223,6 +280,8 @@ class ShardedJoin:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         self.last = {
             "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
+            "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
+            "head_terms": int(self.head.size),
             "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
             "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes,
                          "union": int(uniq.numel()), "all_gather_bytes_per_rank": 8 * max(sizes + [1]) * self.T,

@@ -121,7 +121,21 @@ class ApssIndex:
     def stats(self):
         st = _lib.Stats()
         self._chk(self._L.apss_stats_get(self._h, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in _lib.Stats._fields_}
+        d = {k: getattr(st, k) for k, _ in _lib.Stats._fields_ if k != "reserved0"}
+        d["probe_kernel"] = d["probe_kernel"].decode()
+        return d
+
+    def set_head_terms(self, terms, part=0, n_parts=1):
+        """dense-head block named by the caller (every term shard of a join gets the same terms; shard `part` of `n_parts`
+        multiplies its share of the candidate tiles); empty handle only"""
+        t = _np(terms, np.int32)
+        self._chk(self._L.apss_set_head_terms(self._h, t.size, _ptr(t), int(part), int(n_parts)))
+
+    def head_terms(self):
+        n = C.c_int32(0)
+        out = np.zeros(256, np.int32)
+        self._chk(self._L.apss_get_head_terms(self._h, out.size, _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
 
     def clear(self):
         self._chk(self._L.apss_clear(self._h))

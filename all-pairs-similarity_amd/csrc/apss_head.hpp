@@ -78,6 +78,10 @@ struct HeadPackArgs {
   float *ratio_t;          // [..] |x_T| / |x| per row, indexed like the W rows
   int32_t *idx_tail;       // same extent as idx (may be null): idx with head entries replaced by kNoTerm
   unsigned int *head_nonempty;  // += rows with at least one head entry
+  // a term shard packs W from the batch as the caller handed it in (whole rows; its store keeps its term range only):
+  const float *row_inv;    // [rows of the CSR] or null: factor of every value (APSS_FLAG_NORMALIZE, k_ingest_count)
+  float prune_above;       // an entry counts iff value * row_inv > prune_above (APSS_FLAG_VALUE_PRUNE; -inf: every entry)
+  int32_t part, n_parts;   // head_nonempty counts the rows of the W tiles t % n_parts == part only (n_parts <= 1: every row)
 };
 
 // one wave per W row, 8 rows (one 128-B line per chunk) per workgroup; the workgroup covers W rows [8 g, 8 g + 8)
@@ -95,13 +99,15 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
   if (real) {
     const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
     float full2 = 0.f, h2 = 0.f, t2 = 0.f;
+    const float inv = a.row_inv ? a.row_inv[row] : 1.0f;
     for (int64_t k = b + lane; k < e; k += kWave) {
-      const float v = a.val[k];
+      const float v = a.val[k] * inv;
       const int32_t t = a.idx[k];
       const int32_t hp = a.head_pos[t];
+      if (a.idx_tail) a.idx_tail[k] = hp >= 0 ? (int32_t)kNoTerm : t;
+      if (!(v > a.prune_above)) continue;
       full2 += v * v;
       if (hp >= 0) h2 += v * v; else t2 += v * v;
-      if (a.idx_tail) a.idx_tail[k] = hp >= 0 ? (int32_t)kNoTerm : t;
     }
     for (int o = kWave / 2; o; o >>= 1) {
       full2 += __shfl_xor(full2, o);
@@ -112,12 +118,13 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
     // (LDS operations of one wave execute in order: the zero fill above lands before these entries)
     for (int64_t k = b + lane; k < e; k += kWave) {
       const int32_t hp = a.head_pos[a.idx[k]];
-      if (hp >= 0) rowbuf[wv][hp] = f32_to_bf16_rn(a.val[k] * scale);
+      const float v = a.val[k] * inv;
+      if (hp >= 0 && v > a.prune_above) rowbuf[wv][hp] = f32_to_bf16_rn(v * scale);
     }
     if (lane == 0) {
       // rounded DOWN a hair: the sparse filter divides the row's tail weights by it (errs on the side of reporting more)
-      a.ratio_t[wr] = full2 > 0.f ? fminf(1.0f, sqrtf(t2 / full2)) * 0.999999f : 0.f;
-      if (h2 > 0.f) atomicAdd(&nz, 1u);
+      if (a.ratio_t) a.ratio_t[wr] = full2 > 0.f ? fminf(1.0f, sqrtf(t2 / full2)) * 0.999999f : 0.f;
+      if (h2 > 0.f && (a.n_parts <= 1 || (int32_t)((wr >> 6) % a.n_parts) == a.part)) atomicAdd(&nz, 1u);
     }
   }
   __syncthreads();
@@ -130,6 +137,16 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
       *reinterpret_cast<uint4 *>(a.W + head_chunk_off(w, c, a.kh)) = *reinterpret_cast<const uint4 *>(&rowbuf[j][c * 8]);
   }
   if (threadIdx.x == 0 && nz && a.head_nonempty) atomicAdd(a.head_nonempty, nz);
+}
+
+// the store's term array with the block's entries masked (what the index build reads), entries [k0, k1): a term shard's
+// store is its term range of every row, so the mask is made from the store, not by k_head_pack from the caller's batch
+__global__ void k_head_mask(const int32_t *idx, const int32_t *head_pos, int32_t *idx_tail, int64_t k0, int64_t k1) {
+  const int64_t k = k0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < k1) {
+    const int32_t t = idx[k];
+    idx_tail[k] = head_pos[t] >= 0 ? (int32_t)kNoTerm : t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -156,6 +173,8 @@ struct HeadGemmArgs {
   int64_t q_slot_base;  // slot of query row 0 when the batch is stored in the index, else -1
   int32_t nq;
   int32_t n_qblocks, n_panels, n_ctiles;  // n_ctiles: candidate tiles of head_tile_rows(KH) rows
+  int32_t part, n_parts;  // this launch multiplies the candidate tiles t with t % n_parts == part (the block of a term-sharded
+                          // join is cut over the GPUs by candidate row: 64-row tiles dealt round-robin; 0, 1: every tile)
   int64_t qblock0;      // first query block's first slot (a multiple of 512)
   const int64_t *q_ext, *c_ext;
   float thr;
@@ -197,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
   // panel p = candidate tiles p, p + P, p + 2P, ...: interleaved, so that the triangle of a stored batch (tiles above
   // the query block are skipped: the block that owns them reports the mirrored pairs) is cut evenly over the panels,
   // hence over the XCDs
-  const int t_lo = panel, t_step = a.n_panels;
+  const int t_lo = a.part + a.n_parts * panel, t_step = a.n_parts * a.n_panels;
   int t_hi = a.n_ctiles;
   if (stored) t_hi = min(t_hi, (int)((B0 + kHeadQBlock) / CT));
   if (t_lo >= t_hi) return;
@@ -382,6 +401,7 @@ struct HeadGemvArgs {
   int64_t q_slot_base;
   int32_t nq;
   int32_t kh;
+  int32_t part, n_parts;  // as in HeadGemmArgs
   const int64_t *q_ext, *c_ext;
   float thr;
   int32_t *res_q, *res_c;
@@ -411,7 +431,8 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
       qv[qq][k] = __uint_as_float((uint32_t)b << 16);
     }
     __syncthreads();
-    for (int64_t t = (int64_t)blockIdx.x * 4 + tid / kWave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+    for (int64_t tl = (int64_t)blockIdx.x * 4 + tid / kWave; a.part + tl * a.n_parts < n_tiles; tl += (int64_t)gridDim.x * 4) {
+      const int64_t t = a.part + tl * a.n_parts;
       const int64_t c = t * kHeadCTile + ln;
       float s[kGemvQ];
 #pragma unroll

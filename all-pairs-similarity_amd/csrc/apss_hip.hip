@@ -107,7 +107,10 @@ struct apss_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   bool sharded = false;
-  bool nonneg = true;  // every stored / queried weight so far is >= 0
+  bool nonneg = true;    // every stored weight so far is >= 0
+  bool q_nonneg = true;  // every weight of the staged query batch is >= 0 (decided per call: a signed query batch does not change the handle)
+  bool no_acc8 = false;  // the 8-bit filter proved unusable on this handle's data: 16-bit accumulators until apss_clear
+  uint32_t downgrades = 0;  // APSS_DOWNGRADE_* (apss_stats): permanent fallbacks this handle has taken since the last clear
   int64_t store_max_nnz = 0, q_max_nnz = 0;  // longest row of the store / of the staged query batch
   float store_max_norm2 = 0.f, q_max_norm2 = 0.f;  // largest squared row norm (bounds every partial score)
   int64_t store_nonempty = 0;  // stored rows with at least one indexed entry (each touches itself in a self-join)
@@ -168,6 +171,8 @@ struct apss_handle {
   DevBuf<unsigned int> flagword;
   // dense-head block (apss_head.hpp): the KH most frequent terms live in W instead of the inverted index
   int32_t head_k = 0;                 // 0: no block
+  bool head_fixed = false;            // the block's terms were set through apss_set_head_terms: no policy, kept across apss_clear
+  int32_t head_part = 0, head_parts = 1;  // this handle multiplies the candidate tiles t % head_parts == head_part of the block
   int64_t head_eval_rows = 0;         // store size when the head policy last looked at the term distribution
   bool head_blocked = false;          // a call needed the plain path: no block until the next apss_clear
   std::vector<int32_t> head_terms;    // the block's terms, in block order
@@ -294,6 +299,8 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   a.row_inv = h->s_inv.p;
   a.row_sub = h->s_sub.p;
   a.flags_out = h->flagword.p;
+  const bool shard_head = h->sharded && h->head_k > 0;
+  a.head_pos = shard_head ? h->head_pos.p : nullptr;
   const int threads = 256;
   const int64_t blocks = ceil_div(n * kGroup, threads);
   // (the workgroups loop over their rows: few workgroups = few same-address atomics on the batch summaries)
@@ -319,7 +326,8 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
     return fail(h, APSS_E_INVALID, "malformed vector: indices must be strictly increasing and in [0, dim) "
                                    "(SparseVector.scala:75; vectorDim mismatch is the require of CommonUtils.scala:99)");
   if (flags_host[0] & 2u) return fail(h, APSS_E_INVALID, "non-finite value in a vector");
-  if (flags_host[0] & 4u) h->nonneg = false;
+  if (to_store) h->nonneg = h->nonneg && !(flags_host[0] & 4u);
+  else h->q_nonneg = !(flags_host[0] & 4u);
   float norm2;
   std::memcpy(&norm2, &flags_host[2], sizeof(float));
   if (to_store) {
@@ -366,6 +374,45 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   }
   hipLaunchKernelGGL(k_ingest_write, dim3((unsigned)blocks), dim3(threads), 0, h->stream, w);
   HIPCHK(h, hipGetLastError());
+  if (shard_head) {
+    // the rows of the dense-head block come from the batch as the caller handed it in (whole rows: the store keeps this
+    // shard's term range only); rows map 1:1 (apss_set_head_terms refuses the admission filter on a shard)
+    const int64_t kh = h->head_k;
+    DevBuf<uint16_t> &o_W = to_store ? h->W : h->q_W;
+    const int64_t rows_end = dst_row0 + kept_rows;
+    const int64_t w_pad = to_store ? ceil_div(rows_end, kHeadQBlock) * kHeadQBlock + kHeadCTile : ceil_div(rows_end, kHeadCTile) * kHeadCTile;
+    APSS_TRY(ensure(h, o_W, (size_t)(w_pad * kh), (size_t)(ceil_div(dst_row0, kHeadCTile) * kHeadCTile * kh)));
+    APSS_TRY(ensure(h, h->head_ctr, 4));
+    HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
+    HeadPackArgs p{};
+    p.rowptr = d_rowptr;
+    p.idx = d_idx;
+    p.val = d_val;
+    p.row0 = 0;
+    p.row1 = n;
+    p.head_pos = h->head_pos.p;
+    p.kh = (int32_t)kh;
+    p.W = o_W.p;
+    p.w_row0 = dst_row0;
+    p.w_pad = w_pad;
+    p.ratio_t = nullptr;  // k_ingest_count wrote this shard's ratio
+    p.idx_tail = nullptr;
+    p.head_nonempty = reinterpret_cast<unsigned int *>(h->head_ctr.p);
+    p.row_inv = (h->cfg.flags & APSS_FLAG_NORMALIZE) ? h->s_inv.p : nullptr;
+    p.prune_above = (h->cfg.flags & APSS_FLAG_VALUE_PRUNE) ? (float)h->cfg.index_threshold : -INFINITY;
+    p.part = h->head_part;  // (a stored query's product with itself is counted by the shard that owns its tile)
+    p.n_parts = h->head_parts;
+    hipLaunchKernelGGL(k_head_pack, dim3((unsigned)(ceil_div(w_pad, 8) - dst_row0 / 8)), dim3(512), 0, h->stream, p);
+    HIPCHK(h, hipGetLastError());
+    if (to_store) {
+      unsigned int nz = 0;
+      HIPCHK(h, hipMemcpyAsync(&nz, h->head_ctr.p, sizeof(nz), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (dst_row0 == 0) h->head_nonempty = 0;
+      h->head_nonempty += nz;
+      h->last_batch_head_nonempty = nz;
+    }
+  }
   *n_out = kept_rows;
   *nnz_out = kept_nnz;
   return APSS_OK;
@@ -480,6 +527,7 @@ double acc8_scale(double bound, double shared, double theta) {
 constexpr int64_t kTailMaxRows = 4096;   // rows that may wait outside the tile index (scored pair by pair by k_tail_score)
 constexpr int64_t kTailMaxBatch = 256;   // a batch larger than this extends the index right away
 constexpr int64_t kTailMaxPairs = 1 << 22;  // (queries x tail rows) a probe scores directly; beyond it the tail is folded in first
+constexpr int32_t kHeadMaxTerms = 256;   // widest block (k_head_gemm<256>)
 constexpr int64_t kHeadMinRows = 16384;  // below this a join is over before a GEMM pays for its set-up
 constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse filter (measured, C3)
 // seconds per (query, candidate) element of the head contraction, block width 64 / 128 / 256 (measured on random rows,
@@ -487,8 +535,23 @@ constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse 
 constexpr double kHeadDenseCost[3] = {1.5e-13, 1.9e-13, 3.1e-13};
 constexpr double kHeadSurvivorCost = 1.0e-8;  // seconds per element the dense filter passes on (report + de-dup + exact re-score)
 
+// A plain handle decides for itself (choose_head) unless the block's terms were set through apss_set_head_terms; a term
+// shard only ever takes the terms it was given -- the {H, T_1 .. T_T} partition of the shard rule must be the same on every
+// shard of the join, so the caller that cut the term ranges names the block too.
 inline bool head_allowed(const apss_handle *h) {
-  return h->use_coarse && !h->sharded && h->cfg.head_terms >= 0 && h->cfg.theta > 0.0 && !h->head_blocked && h->nonneg;
+  return h->use_coarse && (!h->sharded || h->head_fixed) && (h->cfg.head_terms >= 0 || h->head_fixed) && h->cfg.theta > 0.0 &&
+         !h->head_blocked && h->nonneg;
+}
+
+// term shard: the store's term array with the block's entries masked, entries of rows [row0, n_rows)
+int32_t head_mask_store(apss_handle *h, int64_t row0, int64_t nnz0) {
+  APSS_TRY(ensure(h, h->idx_tail, (size_t)std::max<int64_t>(h->nnz, 1), (size_t)(row0 ? h->idx_tail_valid : 0)));
+  if (h->nnz > nnz0)
+    hipLaunchKernelGGL(k_head_mask, dim3((unsigned)ceil_div(h->nnz - nnz0, 256)), dim3(256), 0, h->stream,
+                       (const int32_t *)h->idx.p, (const int32_t *)h->head_pos.p, h->idx_tail.p, nnz0, h->nnz);
+  HIPCHK(h, hipGetLastError());
+  h->idx_tail_valid = h->nnz;
+  return APSS_OK;
 }
 
 // W rows, tail ratios and the masked term array for store rows [row0, n_rows)
@@ -516,6 +579,8 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
     a.ratio_t = h->sub.p;
     a.idx_tail = h->idx_tail.p;
     a.head_nonempty = reinterpret_cast<unsigned int *>(h->head_ctr.p);
+    a.row_inv = nullptr;
+    a.prune_above = -INFINITY;  // (the store holds the rows as they are scored)
     hipLaunchKernelGGL(k_head_pack, dim3((unsigned)(ceil_div(rows_pad, 8) - row0 / 8)), dim3(512), 0, h->stream, a);
   }
   HIPCHK(h, hipGetLastError());
@@ -559,6 +624,8 @@ int32_t head_sample_selectivity(apss_handle *h, double *frac) {
   p.ratio_t = h->sub.p;
   p.idx_tail = nullptr;
   p.head_nonempty = nullptr;
+  p.row_inv = nullptr;
+  p.prune_above = -INFINITY;
   hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(p.w_pad, 8)), dim3(512), 0, h->stream, p);
   HIPCHK(h, hipGetLastError());
   ProbeArgs a{};
@@ -658,7 +725,7 @@ int32_t build_index(apss_handle *h, int64_t row0) {
   row0 = std::min(row0, h->idx_rows);  // rows waiting in the tail are folded in with this batch
   h->idx_rows = h->n_rows;
   if (head_allowed(h)) {
-    if (h->n_rows >= std::max<int64_t>(h->cfg.head_terms > 0 ? 1 : kHeadMinRows, 2 * h->head_eval_rows)) {
+    if (!h->head_fixed && h->n_rows >= std::max<int64_t>(h->cfg.head_terms > 0 ? 1 : kHeadMinRows, 2 * h->head_eval_rows)) {
       bool changed = false;
       APSS_TRY(choose_head(h, &changed));
       if (changed) {  // every tile's posting lists change with the term set: rebuild from the first row
@@ -669,9 +736,14 @@ int32_t build_index(apss_handle *h, int64_t row0) {
     }
     if (h->head_k) {
       h->cx.cb = std::min(h->cx.cb, 32768);  // the sparse half runs the 512-thread shard-rule kernel
-      APSS_TRY(head_pack_store(h, row0));
+      if (h->sharded) APSS_TRY(head_mask_store(h, row0, row0 ? h->idx_tail_valid : 0));  // (W and the ratios: ingest)
+      else APSS_TRY(head_pack_store(h, row0));
     }
+  } else if (h->head_k && h->sharded) {
+    // a shard cannot leave the partition its peers were given: the block's terms are in no shard's index
+    return fail(h, APSS_E_UNSUPPORTED, "a term shard with a dense-head block needs non-negative weights (apss_set_head_terms)");
   } else if (h->head_k) {  // e.g. a negative weight arrived: back to the plain index
+    h->downgrades |= APSS_DOWNGRADE_HEAD;
     h->head_k = 0;
     h->head_terms.clear();
     row0 = 0;
@@ -687,12 +759,12 @@ int32_t build_index(apss_handle *h, int64_t row0) {
       h->cx.cb = seg32 < 16.0 && !h->sharded && !h->head_k ? 65536 : 32768;  // (the 1024-thread kernel has no shard variant)
       // sparser still (C5: 6.5): 131072-row tiles with 8-bit accumulators (k_probe_coarse<1024, .., ACC8>) when the norms and
       // row lengths leave room for them: half the segment-descriptor look-ups and half the half-empty posting lines
-      if (h->cx.cb == 65536 && seg32 < 8.0 && h->nonneg && !h->dbgcfg.no_acc8 && h->store_max_nnz <= 512 &&
+      if (h->cx.cb == 65536 && seg32 < 8.0 && h->nonneg && !h->dbgcfg.no_acc8 && !h->no_acc8 && h->store_max_nnz <= 512 &&
           acc8_scale((double)h->store_max_norm2 * 1.0001 + 1e-6, (double)h->store_max_nnz, h->cfg.theta) > 0)
         h->cx.cb = 131072;
       // a term shard's rounds are thin (1/T of every query's terms): 8-bit accumulators hold 65536 candidates in the same
       // 64 KB, i.e. half the rounds at the same two workgroups per CU -- when the norms and row lengths leave room for them
-      if (h->sharded && !h->dbgcfg.no_acc8 &&
+      if (h->sharded && !h->head_k && !h->dbgcfg.no_acc8 && !h->no_acc8 &&
           acc8_scale((double)h->store_max_norm2 * 1.0001 + 1e-6, (double)h->store_max_nnz, h->cfg.theta) > 0)
         h->cx.cb = 65536;
     }
@@ -850,6 +922,8 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
     g.q_slot_base = q_slot_base;
     g.nq = (int32_t)nq;
     g.kh = kh;
+    g.part = h->head_part;
+    g.n_parts = h->head_parts;
     g.q_ext = a.q_ext;
     g.c_ext = h->ext.p;
     g.thr = thr;
@@ -859,10 +933,10 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
     g.res_cap = a.res_cap;
     g.counters = a.counters;
     g.head_pairs = h->head_ctr.p + 1;
-    const int64_t blocks = std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div(n_cand, 256)));
+    const int64_t blocks = std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div(n_cand, 256 * (int64_t)h->head_parts)));
     hipLaunchKernelGGL(k_head_gemv, dim3((unsigned)blocks), dim3(256), 0, h->stream, g);
     HIPCHK(h, hipGetLastError());
-    h->st.head_flops = 2.0 * kh * (double)nq * (double)n_cand;
+    h->st.head_flops = 2.0 * kh * (double)nq * (double)n_cand / (double)h->head_parts;
     return APSS_OK;
   }
   HeadGemmArgs g{};
@@ -879,9 +953,12 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
   g.n_ctiles = (int32_t)ceil_div(n_cand, ct);
   // candidate panels: enough workgroups to fill the chip several times over, a multiple of 8 (= XCDs) so that every
   // workgroup of an XCD streams panels of one residue class, and long enough to amortise the A-fragment load
+  g.part = h->head_part;
+  g.n_parts = h->head_parts;
+  const int64_t my_ctiles = std::max<int64_t>(1, g.n_ctiles / g.n_parts);  // (this handle's share of the candidate tiles)
   int64_t panels = 8;
-  while (panels * g.n_qblocks < 2048 && g.n_ctiles / (2 * panels) >= 32) panels *= 2;
-  panels = std::max<int64_t>(1, std::min<int64_t>(panels, g.n_ctiles));
+  while (panels * g.n_qblocks < 2048 && my_ctiles / (2 * panels) >= 32) panels *= 2;
+  panels = std::max<int64_t>(1, std::min<int64_t>(panels, my_ctiles));
   g.n_panels = (int32_t)panels;
   g.q_ext = a.q_ext;
   g.c_ext = h->ext.p;
@@ -901,7 +978,7 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
   double tiles = 0;
   for (int64_t b = 0; b < g.n_qblocks; ++b) {
     const int64_t hi = q_slot_base >= 0 ? std::min<int64_t>(g.n_ctiles, (g.qblock0 + (b + 1) * kHeadQBlock) / ct) : g.n_ctiles;
-    tiles += (double)hi;
+    tiles += hi > g.part ? (double)ceil_div(hi - g.part, g.n_parts) : 0.0;  // the tiles t < hi with t % n_parts == part
   }
   h->st.head_flops = 2.0 * kh * tiles * (double)ct * (double)kHeadQBlock;
   return APSS_OK;
@@ -927,6 +1004,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.probe_ms = 0;
   h->st.probe_launches = 0;
   h->st.thin_launches = 0;
+  h->st.probe_kernel[0] = 0;
   h->st.head_pairs = h->st.head_survivors = 0;
   h->st.head_ms = h->st.head_flops = 0;
   h->st.head_terms = h->head_k ? (int64_t)h->head_terms.size() : 0;
@@ -940,7 +1018,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const double theta = h->cfg.theta;
   int mode;
   if (!(theta > 0.0)) mode = 2;
-  else if (!h->nonneg || (h->cfg.flags & APSS_FLAG_FORCE_SCAN)) mode = 1;
+  else if (!h->nonneg || (q_slot_first < 0 && !h->q_nonneg) || (h->cfg.flags & APSS_FLAG_FORCE_SCAN)) mode = 1;
   else mode = 0;
 
   // every partial score must fit the fixed-point accumulators: by Cauchy-Schwarz a partial sum of non-negative
@@ -974,13 +1052,14 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // 65536-row tiles (term shards; the sparse regime of a plain handle): the 8-bit filter -- 65536 candidates in 64 KB, two
   // 512-thread workgroups per CU -- if this call's norms and row lengths leave room for its sums
   const bool big_shard_tiles = h->sharded && h->cx.cb > 32768;
-  const double a8_scale = h->cx.cb >= 65536 && mode == 0 && !h->head_k && q_max_nnz <= 512 && !dbg.no_acc8 && !dbg.chunk8
+  const double a8_scale = h->cx.cb >= 65536 && mode == 0 && !h->head_k && q_max_nnz <= 512 && !dbg.no_acc8 && !h->no_acc8 && !dbg.chunk8
                               ? acc8_scale(bound, cx_shared, theta) : 0.0;
   if ((big_shard_tiles || h->cx.cb > 65536) && !(a8_scale > 0)) {
     // not this time (a long row, a large norm, signed weights): back to 16-bit accumulators over smaller tiles, for good
     h->cx.cb = h->sharded ? 32768 : 65536;
     h->cx.n_tiles = 0;
-    h->dbgcfg.no_acc8 = true;
+    h->no_acc8 = true;
+    h->downgrades |= APSS_DOWNGRADE_ACC8;
     APSS_TRY(build_index(h, 0));
     return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_slot_first, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
   }
@@ -990,7 +1069,6 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const double cx_theta_used = std::floor(theta * cx_scale * (1.0 - 1.0 / 2048 - 1e-6));
   const bool coarse_path = h->use_coarse && (mode == 0 || cx_signed) && (cx_selective || a8_scale > 0) && cx_fp16_ok && !forced_general && nq < (1LL << 30) &&
                            !(shard_rule && h->cx.cb > 32768 && !(a8_scale > 0)) &&
-                           (q_max_nnz <= 512 || !h->sharded) &&  // (long queries under the shard rule: the dense-head instantiation only)
                            !dbg.exact_accum && cx_scale > 0 && cx_theta < 65000.0 && (shard_rule || cx_theta - 2 >= 1.0) &&
                            std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
   // rows waiting in the tail are scored pair by pair after the join over the index; that needs the two-pass path's final
@@ -1005,14 +1083,18 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   if (hybrid_wanted && !(coarse_path && mode == 0 && head_thr >= 0.5 * theta)) {
     // this call cannot take the hybrid path (signed or very long queries, norms out of range ...): the dense block's
     // terms go back into the inverted index, for good, and the call runs as on a handle without a block
+    if (h->sharded)  // (a shard cannot leave the partition its peers were given)
+      return fail(h, APSS_E_UNSUPPORTED, "this call needs the plain index (signed weights, norms out of the filter's range, theta <= 0): "
+                                         "not available on a term shard with a dense-head block");
     h->head_blocked = true;
+    h->downgrades |= APSS_DOWNGRADE_HEAD;
     APSS_TRY(build_index(h, 0));
     return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_slot_first, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
   }
   const bool hybrid = hybrid_wanted;
   // the batch's rows of the dense-head block and its tail ratios: the store's were packed when it was indexed; an outside
   // batch (or one waiting in the tail) is packed here
-  if (hybrid && q_slot_base < 0) APSS_TRY(pack_query_head(h, q_rowptr, q_idx, q_val, nq));
+  if (hybrid && q_slot_base < 0 && !h->sharded) APSS_TRY(pack_query_head(h, q_rowptr, q_idx, q_val, nq));  // (a shard's ingest packed them)
   const float *q_sub = !shard_rule ? nullptr : (q_slot_base >= 0 ? h->sub.p + q_slot_base : h->q_sub.p);
 
   ProbeArgs a{};
@@ -1090,6 +1172,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     if (dbg.chunk8) u = 4;
     if (dbg.window && cxv.block == 512 && !cxv.vrows && !cxv.sgn) u = dbg.window;
     if (hybrid_wanted && !dbg.window) {  // the skewed tail of a handle with a dense-head block: full window, prefetched long sweeps
+      u = 5;
+      cxv.longpf = true;
+    }
+    if (cxv.vrows && cxv.shard && !cxv.sgn) {  // long rows (real TF-IDF) on a term shard: the shard-rule instantiation that takes virtual rows
       u = 5;
       cxv.longpf = true;
     }
@@ -1212,6 +1298,20 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     int64_t n_launches = 0, thin_launches = 0;
+    {  // the instantiation this call launches, spelled as rocprofv3 prints it (apss_stats.probe_kernel)
+      auto tf = [](bool b) { return b ? "true" : "false"; };
+      char *nm = h->st.probe_kernel;
+      const size_t cap = sizeof(h->st.probe_kernel);
+      if (coarse_path && cxv.even)
+        snprintf(nm, cap, "k_probe_even<%d, %d, %d, %s, %s, %s>", cxv.block, cxv.u, cxv.block <= 512 ? 128 : 256, tf(cxv.shard), tf(cxv.sgn), tf(cxv.acc8));
+      else if (coarse_path)
+        snprintf(nm, cap, "k_probe_coarse<%d, %d, %d, %d, %s, %d, %s, %s, %s, %s>", cxv.block, cxv.u, cxv.block <= 512 ? 128 : 256,
+                 cxv.block <= 512 ? 512 : 1024, tf(cxv.shard), cxv.chunk, tf(cxv.vrows), tf(cxv.sgn), tf(cxv.longpf), tf(cxv.acc8));
+      else if (wave_path)
+        snprintf(nm, cap, "k_probe_wave<%d, %d, %d, %d, %s, %s>", wave_block, wave_u, wave_longcap, wave_survcap, tf(h->sharded), tf(dbg.diag));
+      else
+        snprintf(nm, cap, "k_probe<%d, %d, %s>", mode, kProbeBlock, tf(gen_fx));
+    }
     for (int64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_launch, ++n_launches) {
       a.tile0 = (int32_t)t0;
       a.n_tiles = (int32_t)std::min<int64_t>(tiles_per_launch, total_tiles - t0);
@@ -1288,7 +1388,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       // accumulators, for good, and run the call again.
       h->cx.cb = h->sharded ? 32768 : 65536;
       h->cx.n_tiles = 0;
-      h->dbgcfg.no_acc8 = true;
+      h->no_acc8 = true;
+      h->downgrades |= APSS_DOWNGRADE_ACC8;
       APSS_TRY(build_index(h, 0));
       return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_slot_first, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
     }
@@ -1304,6 +1405,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     h->out_q = h->res_q.p;
     h->out_c = h->res_c.p;
     h->out_s = h->res_s.p;
+    if (coarse_path && h->sharded) h->st.filter_survivors = h->n_res;  // a shard's survivors are its candidates (phase 2 scores them)
     if (coarse_path && !h->sharded) {
       // exact pass: re-score what the filter(s) let through from the fp32 store and prune at theta
       int64_t n_cand = h->n_res;
@@ -1468,7 +1570,12 @@ int32_t insert_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d
   h->last_nq = 0;
   if (h->n_rows + n > 0x7fffffffLL) return fail(h, APSS_E_INVALID, "more than 2^31 - 1 vectors in one handle");
   int64_t kept_rows = 0, kept_nnz = 0;
+  const bool was_nonneg = h->nonneg;
   APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, true, &kept_rows, &kept_nnz));
+  if (h->sharded && h->head_k && !h->nonneg) {  // refused before anything is committed: the index stays as it was
+    h->nonneg = was_nonneg;
+    return fail(h, APSS_E_UNSUPPORTED, "a term shard with a dense-head block needs non-negative weights (apss_set_head_terms)");
+  }
   const int64_t row0 = h->n_rows;
   h->n_rows += kept_rows;
   h->nnz += kept_nnz;
@@ -1502,6 +1609,8 @@ int32_t pack_query_head(apss_handle *h, const int64_t *rowptr, const int32_t *id
   a.ratio_t = h->q_sub.p;
   a.idx_tail = nullptr;
   a.head_nonempty = nullptr;
+  a.row_inv = nullptr;
+  a.prune_above = -INFINITY;
   hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(q_pad, 8)), dim3(512), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   return APSS_OK;
@@ -1512,7 +1621,7 @@ int32_t query_dev_impl(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_
   int64_t kept_rows = 0, kept_nnz = 0;
   APSS_TRY(ingest(h, n, nnz, d_rowptr, d_idx, d_val, d_ext, false, &kept_rows, &kept_nnz));
   // the batch's rows of the dense-head block and its tail ratios (the store's were packed when it was indexed)
-  if (h->head_k && kept_rows > 0) APSS_TRY(pack_query_head(h, h->q_rowptr.p, h->q_idx.p, h->q_val.p, kept_rows));
+  if (h->head_k && !h->sharded && kept_rows > 0) APSS_TRY(pack_query_head(h, h->q_rowptr.p, h->q_idx.p, h->q_val.p, kept_rows));
   return probe(h, kept_rows, h->q_rowptr.p, h->q_idx.p, h->q_val.p, h->q_ext.p, -1, h->q_max_nnz, h->q_max_norm2, kept_nnz,
                n_results);
 }
@@ -1556,6 +1665,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   h->ex.align = kSegAlign;
   h->cx.cb = std::min(2 * h->cb, 32768);
   if (h->dbgcfg.cx_tile) h->cx.cb = h->dbgcfg.cx_tile;  // experiment hook (multiple of 64, <= 65536)
+  h->no_acc8 = h->dbgcfg.no_acc8;
   h->cx.align = h->dbgcfg.seg_align == 16 ? 16 : kSegAlignC;
   h->cx.coarse = true;
   if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {
@@ -1721,6 +1831,7 @@ int32_t apss_stats_get(apss_handle *h, apss_stats *out) {
   h->st.nnz = h->nnz;
   h->st.tiles = h->use_coarse && h->ex_built_rows < h->idx_rows ? h->cx.n_tiles : ceil_div(h->idx_rows, h->ex.cb);
   h->st.hbm_bytes = (int64_t)h->bytes_reserved;
+  h->st.downgrades = h->downgrades;
   *out = h->st;
   return APSS_OK;
 }
@@ -1775,14 +1886,68 @@ int32_t apss_clear(apss_handle *h) {
   h->last_q_val = nullptr;
   h->last_nq = 0;
   h->nonneg = true;
+  h->q_nonneg = true;
+  h->no_acc8 = h->dbgcfg.no_acc8;
+  h->downgrades = 0;
+  h->idx_tail_valid = 0;
   h->store_max_nnz = 0;
   h->store_max_norm2 = 0.f;
   h->store_nonempty = 0;
-  h->head_k = 0;
-  h->head_terms.clear();
+  if (!h->head_fixed) {  // (terms set through apss_set_head_terms are configuration: they outlive the data)
+    h->head_k = 0;
+    h->head_terms.clear();
+  }
   h->head_eval_rows = 0;
   h->head_blocked = false;
   h->head_nonempty = 0;
+  return APSS_OK;
+}
+
+int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *terms, int32_t part, int32_t n_parts) {
+  APSS_TRY(enter(h));
+  if (h->n_rows != 0) return fail(h, APSS_E_STATE, "apss_set_head_terms: the handle holds vectors (set the block before the first insert or after apss_clear)");
+  if (n_terms < 0 || n_terms > kHeadMaxTerms || (n_terms > 0 && !terms)) return fail(h, APSS_E_INVALID, "apss_set_head_terms: 0 .. 256 terms");
+  if (n_parts < 1 || part < 0 || part >= n_parts) return fail(h, APSS_E_INVALID, "apss_set_head_terms: part must be in [0, n_parts)");
+  if (n_parts > 1 && !h->sharded)
+    return fail(h, APSS_E_INVALID, "apss_set_head_terms: only a term shard multiplies a share of the block (n_parts > 1)");
+  if (n_terms == 0) {
+    h->head_fixed = false;
+    h->head_k = 0;
+    h->head_terms.clear();
+    h->head_part = 0;
+    h->head_parts = 1;
+    return APSS_OK;
+  }
+  if (!h->use_coarse || !(h->cfg.theta > 0.0))
+    return fail(h, APSS_E_UNSUPPORTED, "a dense-head block needs the two-pass join (theta > 0, no EXACT_ACCUM / FORCE_* flag)");
+  if (h->sharded && (h->cfg.flags & APSS_FLAG_ADMISSION))
+    return fail(h, APSS_E_UNSUPPORTED, "a term shard packs the block's rows from the batch row by row: not with APSS_FLAG_ADMISSION");
+  std::vector<int32_t> pos((size_t)h->cfg.dim, -1);
+  for (int32_t i = 0; i < n_terms; ++i) {
+    if (terms[i] < 0 || terms[i] >= h->cfg.dim || pos[(size_t)terms[i]] >= 0)
+      return fail(h, APSS_E_INVALID, "apss_set_head_terms: terms must be distinct and in [0, dim)");
+    pos[(size_t)terms[i]] = i;
+  }
+  APSS_TRY(ensure(h, h->head_pos, (size_t)h->cfg.dim));
+  HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)h->cfg.dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->head_terms.assign(terms, terms + n_terms);
+  h->head_k = n_terms <= 64 ? 64 : (n_terms <= 128 ? 128 : 256);
+  h->head_fixed = true;
+  h->head_blocked = false;
+  h->head_part = part;
+  h->head_parts = n_parts;
+  h->cx.n_tiles = 0;
+  h->ex_built_rows = 0;
+  return APSS_OK;
+}
+
+int32_t apss_get_head_terms(apss_handle *h, int32_t capacity, int32_t *out_terms, int32_t *n_terms) {
+  if (!h || !n_terms) return APSS_E_INVALID;
+  const int32_t n = h->head_k ? (int32_t)h->head_terms.size() : 0;
+  *n_terms = n;
+  if (out_terms)
+    for (int32_t i = 0; i < std::min(n, capacity); ++i) out_terms[i] = h->head_terms[(size_t)i];
   return APSS_OK;
 }
 

@@ -71,6 +71,7 @@ struct IngestArgs {
   int32_t dim, term_lo, term_hi;
   uint32_t flags;  // APSS_FLAG_*
   float theta, index_threshold;
+  const int32_t *head_pos;  // [dim] or null: terms of a shard's dense-head block (>= 0) count for no term range's sub-norm
   // pass-1 outputs
   int64_t *row_keep;  // [n] 0/1
   int64_t *row_cnt;   // [n] kept entries (0 for dropped rows)
@@ -111,7 +112,10 @@ __global__ void k_ingest_count(IngestArgs a) {
     const bool keep = keep_v && t >= a.term_lo && t < a.term_hi;
     if (keep) {
       cnt++;
-      sub += v * v;
+      // (a shard with a dense-head block: the block's terms are a part of their own in the {H, T_1 .. T_T} partition of the
+      // shard rule; an entry of the block that lies in this range is stored for the exact partial score, but |x_g| is the
+      // norm of the range WITHOUT it)
+      if (!a.head_pos || a.head_pos[t] < 0) sub += v * v;
       if (v < 0.f) bad |= 4;
     }
   };

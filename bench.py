@@ -84,7 +84,7 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
     of CommonUtils.scala:98-117 in double), timed on this box's host cores on a bounded query sample."""
     from oracle import oracle
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(avail, 16)  # one GPU's share of the host (the box exposes every core of the machine)
+    cores = min(avail, 16)  # one GPU's share of the host (the box exposes every core of the machine): the headline row
     n = len(rp) - 1
     pilot_q = min(n, cores * 2)
     p = oracle.selfjoin_sample(0, cfg["dim"], cfg["theta"], rp, idx, val, 0, pilot_q, cores)
@@ -96,6 +96,12 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
     rt = oracle.selfjoin_sample(2, cfg["dim"], cfg["theta"], rp, idx, val, 0, max(pilot_q, sample // 4), cores)
     rt_distinct = oracle.selfjoin_sample(0, cfg["dim"], cfg["theta"], rp, idx, val, 0, max(pilot_q, sample // 4), cores)["cand_pairs"]
     opt = oracle.selfjoin_sample(1, cfg["dim"], cfg["theta"], rp, idx, val, 0, min(n, sample * 20), cores)
+    all_cores = None
+    if avail > cores:  # "T = all host cores, core count printed": the same port on every core the process may use
+        s_all = int(min(n, sample * avail // cores))
+        ra = oracle.selfjoin_sample(0, cfg["dim"], cfg["theta"], rp, idx, val, 0, s_all, avail)
+        all_cores = {"value": ra["cand_pairs"] / ra["seconds"], "cores": avail,
+                     "sample": "first %d queries, %.1f s, %d threads" % (s_all, ra["seconds"], avail)}
     return {
         "value": r["cand_pairs"] / r["seconds"], "unit": "scored candidate pairs/s", "cores": cores, "kind": "port",
         "sample": "all %d vectors indexed, first %d queries timed (%.1f s, %d threads: queries split by range, every "
@@ -106,22 +112,32 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
             "note": "%d workers, worker t owns dims with dim %% %d == t and re-scores every pair it reaches "
                     "(EntryProxyActor.scala:41-46, IWA:92); distinct pairs of the first %d queries / wall time"
                     % (cores, cores, max(pilot_q, sample // 4))},
+        "all_host_cores": all_cores if all_cores else {"value": r["cand_pairs"] / r["seconds"], "cores": cores,
+                                                        "sample": "the process may use %d cores: same as the headline row" % avail},
         "optimised_cpu_value": opt["cand_pairs"] / opt["seconds"],
         "optimised_cpu_note": "fairness bracket: CSC + dense double accumulator, %d threads" % cores,
     }
 
 
-def profile_quote(workload, n_override, tile_rows, alg_bytes):
-    """HBM-side bytes and SQ counters of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the
-    committed summary of the same command (profiles/collect_r02.sh -> profiles/r02_probe_traffic.json) is quoted when
-    the workload matches byte for byte."""
-    path = os.path.join(ROOT, "profiles", "r02_probe_traffic.json")
-    if n_override or tile_rows or not os.path.exists(path):
+PROBE_TRAFFIC = os.path.join(ROOT, "profiles", "r03_probe_traffic.json")
+
+
+def profile_quote(workload, n_override, tile_rows, alg_bytes, kernel):
+    """HBM-side bytes and SQ counters of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
+    committed summary of the same command (profiles/collect_r03.sh -> profiles/r03_probe_traffic.json) is quoted -- only
+    when the workload matches byte for byte AND the kernel that ran here (apss_stats.probe_kernel) is the kernel the
+    counters were collected on; anything else is refused (traffic: null), never quoted from another kernel."""
+    if n_override or tile_rows or not os.path.exists(PROBE_TRAFFIC):
         return None
-    tj = json.load(open(path))
+    tj = json.load(open(PROBE_TRAFFIC))
     ent = tj.get(workload)
     if not ent or ent.get("algorithmic_bytes_per_launch") != alg_bytes:
         return None
+    counted_on = ent.get("detail", {}).get("kernels", {}).get("filter", {}).get("kernel", "")
+    if not kernel or ("apss::" + kernel) not in counted_on:
+        return None
+    ent = dict(ent)
+    ent["counted_on"] = {"kernel": counted_on, "csrc_git": tj.get("csrc_git")}
     return ent
 
 
@@ -164,10 +180,11 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
     probe_s, head_s = mean("probe_ms") * 1e-3, mean("head_ms") * 1e-3
     alg_bytes = BYTES_PER_VISIT * visits
     hybrid = st["head_terms"] > 0
-    filter_kernel = "k_probe_coarse (16-bit LDS accumulators, 4-B postings) + k_rescore" if st["filter_survivors"] or not visits \
-        else "k_probe_wave / k_probe"
-    if st.get("thin_launches"):
-        filter_kernel = "k_probe_even (F staging waves, chunks dealt evenly over the adding waves; LDS accumulators, 4-B postings) + k_rescore"
+    filter_kernel = st.get("probe_kernel", "")
+    if filter_kernel.startswith("k_probe_even"):
+        filter_kernel += " (F staging waves, chunks dealt evenly over the adding waves; LDS accumulators, 4-B postings) + k_rescore"
+    elif filter_kernel.startswith("k_probe_coarse"):
+        filter_kernel += " (16-bit LDS accumulators, 4-B postings) + k_rescore"
     out = {
         "value": cands / sec_per_step,
         "ms_per_step": sec_per_step * 1e3,
@@ -182,9 +199,9 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
         "filter_survivors": st["filter_survivors"],
     }
     sparse_frac = (alg_bytes / launches / (probe_s / launches) / 1e9) / HBM_PEAK_GBS if probe_s > 0 else None
-    quote = profile_quote(a.workload, a.n, a.tile_rows, alg_bytes)
+    quote = profile_quote(a.workload, a.n, a.tile_rows, alg_bytes, st.get("probe_kernel", ""))
     sparse_roof = {
-        # what the counters show (profiles/r02_sq_counters.txt): the filter kernel's busiest unit is the LDS pipeline
+        # what the counters show (profiles/r0N_probe_traffic.json): the filter kernel's busiest unit is the LDS pipeline
         # (returning 16-bit atomics + clears), not HBM; `frac` stays the SURVEY 8(d) accounting figure (8 B per visit)
         "bound": "lds", "kernel": filter_kernel,
         "achieved": alg_bytes / probe_s / 1e9 if probe_s > 0 else None,
@@ -201,9 +218,10 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
             "measured_frac": traffic / (probe_s / launches) / 1e9 / HBM_PEAK_GBS,
             "measured_frac_of_copy_peak": traffic / (probe_s / launches) / 1e9 / HBM_COPY_GBS,
             "traffic_note": "bytes per launch at the L2 <-> fabric boundary, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate "
-                            "rocprofv3 --pmc passes of this command (profiles/r02_probe_traffic.json); gfx950 tallies 128-B read "
+                            "rocprofv3 --pmc passes of this command (profiles/r03_probe_traffic.json); gfx950 tallies 128-B read "
                             "requests at 64 B; Infinity-Cache hits are included, HBM itself sees each posting once per step",
             "lds_issue_frac": quote.get("lds_issue_frac"), "valu_busy_frac": quote.get("valu_busy_frac"),
+            "counted_on": quote["counted_on"],
         })
     if hybrid:
         flops = st["head_flops"]
@@ -267,9 +285,10 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
 
     def timed(T, label):
         wd.phase = label
-        sj = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev, term_shards=T)
+        sj = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev, term_shards=T,
+                         head_terms=a.head_terms)
         sj.load(rp, idx, val)
-        probe_ms, build_ms = [], []
+        probe_ms, build_ms, head_ms = [], [], []
         for _ in range(a.warmup):
             sj.step()
         sync()
@@ -278,11 +297,17 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
             n_pairs = sj.step()
             probe_ms.append(sj.last["probe_ms"])
             build_ms.append(sj.last["build_ms"])
+            head_ms.append(sj.last.get("head_ms", 0.0))
         sync()
-        t = torch.tensor([time.perf_counter() - t0, float(np.mean(probe_ms)), float(np.mean(build_ms))], dtype=torch.float64,
+        hm_mine = float(np.mean(head_ms))
+        # (the dense-head kernel of the slowest rank, with THAT rank's flops: the rate is a per-GPU figure)
+        t = torch.tensor([time.perf_counter() - t0, float(np.mean(probe_ms)), float(np.mean(build_ms)), hm_mine], dtype=torch.float64,
                          device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank
-        dt, pm, bm = (float(x) for x in t.tolist())
+        dt, pm, bm, hm = (float(x) for x in t.tolist())
+        hf = torch.tensor([sj.last.get("head_flops", 0.0) if hm_mine >= hm else 0.0], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(hf, op=dist.ReduceOp.MAX)
+        head_flops = float(hf.item())
         sec = dt / a.steps
         row = {
             "grid": "%d term-range shards x %d candidate ranges" % (sj.T, sj.D),
@@ -295,11 +320,24 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
                             "per step: all-reduce of counters only (result sets of different candidate ranges are disjoint)"),
         }
         visits = sj.last["posting_visits"]
-        row["roofline"] = {"bound": "lds", "kernel": ("k_probe_even" if sj.last.get("thin_launches") else "k_probe_coarse") + ("<SHARD>" if sj.T > 1 else ""),
-                           "achieved": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 if pm > 0 else None,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s (per GPU: slowest shard's kernel, 1/N of the job's 8-B posting visits)",
-                           "frac": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS if pm > 0 else None,
-                           "traffic": None}
+        sparse_roof = {"bound": "lds", "kernel": sj.last.get("probe_kernel") or "k_probe_coarse",
+                       "achieved": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 if pm > 0 else None,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s (per GPU: slowest shard's kernel, 1/N of the job's 8-B posting visits)",
+                       "frac": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS if pm > 0 else None,
+                       "traffic": None}
+        row["roofline"] = sparse_roof
+        if sj.last.get("head_terms") and hm > 0:
+            # skewed terms: the join's dense-head block, cut over the term group's ranks by candidate tile (apss/dist.py)
+            kh = 64 if sj.last["head_terms"] <= 64 else (128 if sj.last["head_terms"] <= 128 else 256)
+            head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d> (v_mfma_f32_32x32x16_bf16), candidate tiles t %% %d == rank" % (kh, sj.T),
+                         "achieved": head_flops / (hm * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s (per GPU: the slowest rank's kernel and that rank's flops)",
+                         "frac": head_flops / (hm * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None}
+            row.update({"head_terms": sj.last["head_terms"], "head_kernel_ms_slowest_rank": hm})
+            if hm >= pm:
+                row["roofline"], row["roofline_sparse_filter"] = head_roof, sparse_roof
+            else:
+                row["roofline_dense_head"] = head_roof
         del sj.engine
         del sj
         torch.cuda.empty_cache()
@@ -323,6 +361,9 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
         "build_ms": head["build_ms_slowest_shard"], "probe_kernel_ms": head["probe_kernel_ms_slowest_shard"],
         "roofline": head["roofline"],
     }
+    for k in ("roofline_dense_head", "roofline_sparse_filter", "head_terms", "head_kernel_ms_slowest_rank"):
+        if k in head:
+            out[k] = head[k]
     return out, head["grid"] + "; " + head["collectives"], extra
 
 

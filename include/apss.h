@@ -63,8 +63,12 @@ typedef struct apss_config {
   int32_t device_id;       /* HIP device ordinal */
   int32_t term_lo;         /* term-range shard [term_lo, term_hi): only these dims are indexed and scored */
   int32_t term_hi;         /*   (0, 0) or (0, dim) = the whole term space (single GPU) */
-  int32_t tile_rows;       /* candidate tile = rows whose fp32 accumulators share one workgroup's LDS;
-                              0 = default (16384: two workgroups share a CU's 160 KB of LDS); a multiple of 64, <= 32768 */
+  int32_t tile_rows;       /* candidate tile of the EXACT rendering of the index (8-B postings, u32 / fp32 accumulators in one
+                              workgroup's LDS: k_probe_wave, k_probe): 0 = default (16384 rows: two workgroups share a CU's
+                              160 KB of LDS), else a multiple of 64, <= 32768.  The coarse rendering the two-pass join filters
+                              with has tiles of min(2 * tile_rows, 32768) rows (16-bit accumulators); with tile_rows == 0 the
+                              library may pick 65536 (sparse regime, term shards with 8-bit accumulators) or 131072 rows
+                              (sparser still) from the data: apss_stats.tiles says what it took */
   int32_t head_terms;      /* dense-head block: 0 = the library decides from the term distribution, -1 = never,
                               64 | 128 | 256 = always that many of the most frequent terms.  Terms in the block are scored
                               by a bf16 MFMA contraction instead of their posting lists; results are the same set */
@@ -94,7 +98,18 @@ typedef struct apss_stats {
   double head_flops;        /* 2 * KH * (query slots x candidate rows actually multiplied) of the last call */
   int64_t thin_launches;    /* probe launches of the last call that took the thin-round filter kernel (k_probe_even: a term
                                shard's or a sparse batch's rounds of a few hundred postings) */
+  uint32_t downgrades;      /* APSS_DOWNGRADE_*: permanent fallbacks (until apss_clear) this handle took because of a call it could
+                               not serve on its fast layout; each costs one full index rebuild when it happens */
+  uint32_t reserved0;
+  char probe_kernel[64];    /* the probe kernel instantiation the last query-type call launched, as rocprofv3 prints its name up
+                               to the template arguments' spelling, e.g. "k_probe_even<512,6,128,0,0,0>" (threads, window steps,
+                               long-segment list, shard rule, signed, 8-bit accumulators); "" before any probe */
 } apss_stats;
+
+#define APSS_DOWNGRADE_ACC8 1u /* 8-bit accumulators over 65536 / 131072-row tiles given up (a long row, a large norm, an
+                                  unselective byte filter): 16-bit accumulators over smaller tiles */
+#define APSS_DOWNGRADE_HEAD 2u /* the dense-head block was given up (signed weights, norms out of range): its terms are back
+                                  in the inverted index */
 
 /* ---- lifetime (actor construction / stop, IWA:21-39) ---- */
 int32_t apss_create(const apss_config *cfg, apss_handle **out);
@@ -165,6 +180,23 @@ int32_t apss_results_copy_dev(apss_handle *h, int64_t offset, int64_t count, int
  * thresholded.  Pairs are (query row of the last query batch, candidate slot). */
 int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *d_q_row,
                                 const int32_t *d_c_slot, float *d_out_partial);
+
+
+/* ---- dense-head block set by the caller ----
+ * The `n_terms` (<= 256) most frequent terms are scored by a bf16 MFMA contraction over W = [rows x n_terms] instead of
+ * their posting lists (CommonUtils.scala:110-115 restricted to those dims; a FILTER: survivors are re-scored exactly).
+ * On a plain handle this replaces the library's own choice (apss_config.head_terms).  On a TERM SHARD it is the only way
+ * to get a block: every shard of a join must be given the SAME terms -- they are a part of their own, {H, T_1 .. T_T}, in
+ * the partition the candidate rule above is proved for, so a head term lies in no shard's inverted index (it stays in the
+ * store of the shard whose range holds it, for the exact partial scores of phase 2) -- and shard `part` of `n_parts`
+ * multiplies the 64-row candidate tiles t with t % n_parts == part of the contraction against the whole query batch
+ * (the block is cut over the GPUs by candidate row, not by term).  A query-type call on such a shard reports the union of
+ * both filters' candidates (duplicates possible).  Valid on an empty handle only (before the first insert / after
+ * apss_clear); the setting survives apss_clear; n_terms == 0 removes it.  Shards: non-negative weights, no
+ * APSS_FLAG_ADMISSION (APSS_E_UNSUPPORTED otherwise). */
+int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *terms, int32_t part, int32_t n_parts);
+/* the block's terms in block order (chosen by the library or set by the caller); *n_terms = how many there are */
+int32_t apss_get_head_terms(apss_handle *h, int32_t capacity, int32_t *out_terms, int32_t *n_terms);
 
 #ifdef __cplusplus
 }

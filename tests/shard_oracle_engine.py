@@ -5,27 +5,52 @@ import torch
 
 
 class OracleShardEngine:
-    def __init__(self, dim, theta, term_range):
+    """head = (terms, part, n_parts): the join's dense-head block (apss.dist module docstring) -- its terms are in no
+    shard's tail test; this shard runs the head test on the 64-row candidate tiles t with t % n_parts == part."""
+
+    def __init__(self, dim, theta, term_range, head=None):
         self.dim, self.theta, self.lo, self.hi = dim, theta, term_range[0], term_range[1]
+        self.head = head
         self.stats = {}
 
     def load(self, rp, idx, val, row_range=None):
         import scipy.sparse as sp
         n = len(rp) - 1
         x = sp.csr_matrix((val, idx, rp), shape=(n, self.dim), dtype=np.float64)
-        self.xs = x[:, self.lo:self.hi].tocsr()  # the shard's slice of every vector
-        self.sub = np.sqrt(np.asarray(self.xs.multiply(self.xs).sum(axis=1)).ravel())
+        self.xs = x[:, self.lo:self.hi].tocsr()  # the shard's slice of every vector (exact partial scores: head terms included)
+        self.full = np.sqrt(np.asarray(x.multiply(x).sum(axis=1)).ravel())
+        self.xt = self.xs
+        self.w = None
+        if self.head is not None:
+            is_head = np.zeros(self.dim, bool)
+            is_head[np.asarray(self.head[0])] = True
+            mask = sp.diags((~is_head[self.lo:self.hi]).astype(np.float64))
+            self.xt = (self.xs @ mask).tocsr()  # the tail test's slice: the range without the block's terms
+            xh = x[:, np.asarray(self.head[0])].tocsr()
+            hn = np.sqrt(np.asarray(xh.multiply(xh).sum(axis=1)).ravel())
+            self.w = sp.diags(np.where(hn > 0, self.full / np.where(hn > 0, hn, 1.0), 0.0)) @ xh  # w_x = x_H |x| / |x_H|
+        self.sub = np.sqrt(np.asarray(self.xt.multiply(self.xt).sum(axis=1)).ravel())
         self.n = n
         self.r0, self.r1 = (0, n) if row_range is None else row_range
 
     def candidates(self):
-        g = (self.xs @ self.xs[self.r0:self.r1].T).tocoo()  # queries: all rows; candidates: this shard's rows
+        g = (self.xt @ self.xt[self.r0:self.r1].T).tocoo()  # queries: all rows; candidates: this shard's rows
         col = g.col + self.r0
         off = g.row != col
         r, c, v = g.row[off], col[off], g.data[off]
-        keep = v >= self.theta * self.sub[r] * self.sub[c] * 0.999999
+        # p_g >= theta |q_g||c_g| / (|q||c|)
+        keep = v * self.full[r] * self.full[c] >= self.theta * self.sub[r] * self.sub[c] * 0.999999
         self.stats = {"posting_visits": 0, "candidate_pairs": int(off.sum())}
-        return torch.from_numpy(r[keep].astype(np.int64)), torch.from_numpy(c[keep].astype(np.int64))
+        r, c = r[keep], c[keep]
+        if self.w is not None:
+            rows = np.arange(self.r0, self.r1)
+            mine = rows[((rows - self.r0) // 64) % self.head[2] == self.head[1]]  # this shard's candidate tiles (by slot)
+            gh = (self.w @ self.w[mine].T).tocoo()
+            hc = mine[gh.col]
+            bound = float(self.full.max()) ** 2
+            hk = (gh.row != hc) & (gh.data >= self.theta - 0.008 * bound)
+            r, c = np.concatenate([r, gh.row[hk]]), np.concatenate([c, hc[hk]])
+        return torch.from_numpy(r.astype(np.int64)), torch.from_numpy(c.astype(np.int64))
 
     def partial(self, q, c):
         q, c = q.numpy(), c.numpy()

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(so):
 
 def test_config_struct_matches_header():
     assert ctypes.sizeof(_lib.Config) == 64
-    assert ctypes.sizeof(_lib.Stats) == 144
+    assert ctypes.sizeof(_lib.Stats) == 216
 
 
 def test_no_cpu_fallback(so):
@@ -61,3 +61,22 @@ def test_one_hip_runtime_whatever_the_import_order(so):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-1000:]
     assert out.stdout.split() == ["1", "1", "True"], out.stdout
+
+
+def test_every_included_header_is_in_the_staleness_list():
+    """an edit to any file libapss_hip.so is compiled from must rebuild it: the #include "..." closure of apss_hip.hip is
+    inside _lib.build_sources(), and the Makefile names the same files"""
+    csrc = _lib.CSRC
+    seen, todo = set(), [os.path.join(csrc, "apss_hip.hip")]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(f).read(), re.M):
+            todo.append(os.path.join(os.path.dirname(f), inc))
+    srcs = {os.path.normpath(s) for s in _lib.build_sources()}
+    assert seen <= srcs, seen - srcs
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    rule = re.search(r"^libapss_hip\.so:(.*)$", mk, re.M).group(1).split()
+    assert {os.path.normpath(os.path.join(csrc, d)) for d in rule} == seen, (rule, seen)

@@ -12,7 +12,15 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, out_dir, term_shards):
+def _top_df(k):
+    """stand-in for the library's head policy on CPU: the k most frequent terms"""
+    def choose(rp, idx, val):
+        df = np.bincount(idx)
+        return np.argsort(-df, kind="stable")[:k].astype(np.int32)
+    return choose
+
+
+def _worker(rank, world, port, out_dir, term_shards, head_k=0):
     sys.path[:0] = [os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "all-pairs-similarity_amd"), HERE]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -23,8 +31,13 @@ def _worker(rank, world, port, out_dir, term_shards):
     n, dim, nnz, theta = 1500, 400, 14, 0.6
     rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=77, dup_frac=0.1)
     sj = ShardedJoin(dim, theta, rank, world, torch.device("cpu"), term_shards=term_shards,
-                     engine_factory=lambda tr: OracleShardEngine(dim, theta, tr))
+                     engine_factory=lambda tr, head=None: OracleShardEngine(dim, theta, tr, head),
+                     head_terms=head_k if head_k else -1, head_chooser=_top_df(head_k))
     sj.load(rp, idx, val)
+    assert sj.head.size == (head_k if term_shards > 1 else 0)
+    if head_k and term_shards > 1:  # the block's terms are in no shard's tail test, and every rank holds the same block
+        assert sj.engine.head[1:] == (rank % term_shards, term_shards)
+        assert float(abs(sj.engine.xt[:, [t - sj.term_range[0] for t in sj.head if sj.term_range[0] <= t < sj.term_range[1]]]).sum()) == 0.0
     q, c, s = sj.step(return_pairs=True)
     total = sj.step()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), q=q, c=c, s=s, lo=sj.term_range[0], hi=sj.term_range[1],
@@ -32,14 +45,16 @@ def _worker(rank, world, port, out_dir, term_shards):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,term_shards", [(2, 2), (3, 3), (4, 2), (2, 1)])
-def test_sharded_join_matches_oracle(tmp_path, oracle, world, term_shards):
+@pytest.mark.parametrize("world,term_shards,head_k", [(2, 2, 0), (3, 3, 0), (4, 2, 0), (2, 1, 0), (2, 2, 12), (4, 2, 12), (3, 3, 40)])
+def test_sharded_join_matches_oracle(tmp_path, oracle, world, term_shards, head_k):
     """T term shards x D candidate ranges: union over the D groups == the oracle's result; inside a group every rank
-    holds the identical group result (all-reduced partial scores)"""
+    holds the identical group result (all-reduced partial scores).  head_k > 0: the join's dense-head block -- rank 0's
+    choice broadcast to every rank, the block's terms out of every tail range, its test cut over the group's ranks by
+    candidate tile (Zipf(1) terms: the block holds most of a typical row's weight)"""
     from apss import synth
     from helpers import assert_same_pairs, to_map
-    port = 29500 + (os.getpid() % 2000) + 7 * world + term_shards
-    mp.spawn(_worker, args=(world, port, str(tmp_path), term_shards), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * world + term_shards + 31 * (head_k > 0) + head_k
+    mp.spawn(_worker, args=(world, port, str(tmp_path), term_shards, head_k), nprocs=world, join=True)
     n, dim, nnz, theta = 1500, 400, 14, 0.6
     rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=77, dup_frac=0.1)
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
