@@ -101,7 +101,7 @@ typedef struct apss_stats {
   uint32_t downgrades;      /* APSS_DOWNGRADE_*: permanent fallbacks (until apss_clear) this handle took because of a call it could
                                not serve on its fast layout; each costs one full index rebuild when it happens */
   uint32_t reserved0;
-  char probe_kernel[64];    /* the probe kernel instantiation the last query-type call launched, as rocprofv3 prints its name up
+  char probe_kernel[96];    /* the probe kernel instantiation the last query-type call launched, as rocprofv3 prints its name up
                                to the template arguments' spelling, e.g. "k_probe_even<512,6,128,0,0,0>" (threads, window steps,
                                long-segment list, shard rule, signed, 8-bit accumulators); "" before any probe */
 } apss_stats;

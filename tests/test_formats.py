@@ -134,3 +134,28 @@ def test_tfidf_ingest_matches_the_etl_restatement(host_formats, oracle, tmp_path
     # the known hash values: "" -> 0, "a" -> 97, "null" -> 3392903 (java.lang.String.hashCode)
     assert oracle.java_string_hash("") == 0 and oracle.java_string_hash("a") == 97 and oracle.java_string_hash("null") == 3392903
     assert oracle.java_string_hash("polygenelubricants") == -2147483648 and oracle.non_negative_mod(-2147483648, 1 << 20) == 0
+
+
+def test_full_corpus_c1_fixture_is_what_the_oracle_says(oracle):
+    """tests/golden/maildir_full_counts.npz (all 8,586 mail documents as term counts + the oracle's pair list): the weights
+    derived from the counts reproduce the committed pairs on a query sample -- the fixture is the oracle's output, not
+    something else's -- and the stride-12 fixture of round 1 is a subset of the same corpus (same rows, same weights)"""
+    import os
+    import maildir_full
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z, rp, idx, cnt = maildir_full.load(os.path.join(g, "maildir_full_counts.npz"))
+    val = maildir_full.weights(rp, idx, cnt)
+    dim, theta = int(z["dim"]), float(z["theta"])
+    nq = 300
+    q, c, s = oracle.selfjoin_pairs(dim, theta, rp, idx, val, 0, nq)
+    got = {(int(a), int(b)): float(v) for a, b, v in zip(q, c, s)}
+    want = {(int(a), int(b)): float(v) for a, b, v in zip(z["out_q"], z["out_c"], z["out_sim"]) if a < nq}
+    assert got.keys() == want.keys() and len(want) > 100
+    assert max(abs(got[k] - want[k]) for k in want) < 1e-12
+    small = np.load(os.path.join(g, "maildir_small_tfidf.npz"))
+    stride = int(small["stride"])
+    for j in (0, 5, 700):
+        r = j * stride
+        a = slice(small["rowptr"][j], small["rowptr"][j + 1])
+        b = slice(rp[r], rp[r + 1])
+        assert np.array_equal(small["indices"][a], idx[b]) and np.abs(small["values"][a] - val[b]).max() < 1e-7

@@ -236,5 +236,34 @@ def test_maildir_tfidf_through_term_shards():
         engines = _shard_engines(dim, theta, idx, 4, head, rp=rp, val=val)
         q, c, s, n_cand = join_shards_local(engines, n, theta)
         assert_same_pairs(to_map(q, c, s), want, theta)
-        for e in engines:
-            assert e.stats["filter_survivors"] > 0 and e.stats["probe_kernel"].startswith("k_probe_coarse<512, 5, 128, 512, true, 16, true"), e.stats
+        kernels = [e.stats["probe_kernel"] for e in engines]
+        for e in engines:  # every shard went through the filter (a shard's survivors are its candidates) ...
+            assert e.stats["filter_survivors"] > 0 and e.stats["probe_kernel"].startswith(("k_probe_coarse<", "k_probe_even<")), e.stats
+        # ... and where a shard's slice of some row still has more than 512 terms, through its virtual-row instantiation
+        assert any(k.startswith("k_probe_coarse<512, 5, 128, 512, true, 16, true") for k in kernels), kernels
+
+
+def test_c1_every_document_plain_and_through_term_shards():
+    """BASELINE config 1 at FULL size: all 8,586 documents of data/maildir_small as TF-IDF vectors (HashingTF 2^20, rows of up
+    to 6,138 terms), theta = 0.7 -- on one plain handle, then through four term-range shards (long rows through the filter's
+    virtual-row instantiation).  The fixture holds term counts + the oracle's pair list (tests/golden/make_maildir_full.py);
+    the weights are derived by the function the generator fed the oracle with"""
+    import maildir_full
+    from apss.dist import join_shards_local
+    from apss.engine import ApssIndex
+    z, rp, idx, cnt = maildir_full.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maildir_full_counts.npz"))
+    val = maildir_full.weights(rp, idx, cnt)
+    dim, theta, n = int(z["dim"]), float(z["theta"]), len(rp) - 1
+    assert n == 8586 and int(np.diff(rp).max()) == 6138
+    want = to_map(z["out_q"], z["out_c"], z["out_sim"])
+    assert len(want) == 39472
+    with ApssIndex(dim, theta) as ix:
+        got = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
+        st = ix.stats()
+    assert_same_pairs(got, want, theta)
+    assert st["filter_survivors"] > 0 and st["probe_kernel"].startswith("k_probe_coarse<"), st
+    engines = _shard_engines(dim, theta, idx, 4, None, rp=rp, val=val)
+    q, c, s, n_cand = join_shards_local(engines, n, theta)
+    assert_same_pairs(to_map(q, c, s), want, theta)
+    for e in engines:
+        assert e.stats["filter_survivors"] > 0 and e.stats["probe_kernel"].startswith(("k_probe_coarse<", "k_probe_even<")), e.stats
