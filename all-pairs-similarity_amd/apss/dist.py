@@ -54,7 +54,7 @@ def term_ranges(df, world):
 def hip_head_chooser(dim, theta, device, head_terms=0, sample_rows=131072):
     """The dense-head block of a sharded join, decided by the library's own policy (choose_head in csrc/apss_hip.hip:
     sampled document frequencies, measured selectivity) on the first `sample_rows` rows of the batch: a plain handle
-    indexes the sample and is asked which terms it took.  head_terms: 0 = policy, 64 | 128 | 256 = that many."""
+    indexes the sample and is asked which terms it took.  head_terms: 0 = policy, 64 | 128 | 256 | 512 | 1024 = that many."""
     def choose(rp, idx, val):
         from .engine import ApssIndex
         m = int(min(len(rp) - 1, sample_rows))
@@ -163,7 +163,7 @@ class ShardedJoin:
     eight candidate ranges 6.0x); candidate ranges need no data-path collective.  `term_shards` = T picks the layout:
     bench.py's headline is T = world (the layout BASELINE.json names), this class's default T = 1.
     head_terms: dense-head block of the term-sharded layouts (module docstring): 0 = the library's policy decides on rank 0,
-    -1 = never, 64 | 128 | 256 = that many of the most frequent terms.  (With T = 1 every handle is a plain one and decides
+    -1 = never, 64 | 128 | 256 | 512 | 1024 = that many of the most frequent terms.  (With T = 1 every handle is a plain one and decides
     for itself.)"""
 
     def __init__(self, dim, theta, rank, world, device, tile_rows=0, engine_factory=None, comm_device=None,
@@ -191,9 +191,9 @@ class ShardedJoin:
 
     def _decide_head(self, rp, idx, val):
         """rank 0 asks the policy, every rank gets the same terms (one broadcast at load time, not in the data path)"""
-        buf = torch.zeros(257, dtype=torch.int32, device=self.comm)
+        buf = torch.zeros(8193, dtype=torch.int32, device=self.comm)
         if self.rank == 0:
-            t = np.asarray(self.head_chooser(rp, idx, val), dtype=np.int32)[:256]
+            t = np.asarray(self.head_chooser(rp, idx, val), dtype=np.int32)[:8192]
             buf[0] = int(t.size)
             if t.size:
                 buf[1:1 + t.size] = torch.from_numpy(t).to(self.comm)

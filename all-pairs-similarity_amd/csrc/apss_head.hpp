@@ -20,6 +20,23 @@
 // re-scored exactly over the FULL rows by k_rescore (CommonUtils.scala:98-117) and pruned at theta
 // (IndexingWorkerActor.scala:93), exactly as the survivors of the plain two-pass join are.
 //
+// Wider heads = a second, FOLDED block.  The rule above holds for any partition of the terms, so the head may be two parts
+// H_1 (the 256 most frequent terms, one column each, as above) and H_2 (the next 256 F terms), each with its own rows
+// w_c^b = c_{H_b} |c| / |c_{H_b}| and its own test  w_q^b . w_c^b >= theta.  H_2's rows are FOLDED into 256 columns: term
+// number i of H_2 adds into column i mod 256, and the test uses the dot product of the folded rows.  With non-negative
+// weights that is an UPPER bound of the true partial dot over H_2 --
+//     sum_col (sum_{t in col} q_t) (sum_{t in col} c_t)  >=  sum_t q_t c_t        (the cross terms are >= 0)
+// -- so no pair the exact test would pass is lost, and what it passes in excess (two rows holding DIFFERENT terms of one
+// column) is bounded by the rows' other entries: a row holds m ~ 10-40 of H_2's terms, a chance pair collides in ~m^2/256
+// columns, each worth ~1/m of the block's cosine, i.e. ~m/256 in all -- far below theta.  Every candidate is re-scored
+// exactly anyway.  Cost: ONE more contraction of width 256, whatever F -- while the posting visits the inverted index keeps
+// fall like 1 / (256 (1 + F)) under a Zipfian term distribution, and with them the long segments the sparse filter is
+// slowest on.  (Several EXACT blocks of 256 were measured first: blocks 2..4 of a 1024-term head hold 2-6 terms of a row
+// each, rows with a single term of a block pair up at cosine 1, and the blocks passed 4e7 .. 1.5e9 chance pairs on C3 with
+// Zipf(1) terms -- thin blocks lose the rule's selectivity, folding restores it.  A single contraction of width 512 or 1024
+// would need the A fragments of 64 query slots x 1024 terms = 512 VGPRs per lane.)  W holds a row's two blocks side by side:
+// with the chunk-major tile layout a tile is 64 rows x 512 columns and block b is the contiguous 32-KB piece b of the tile.
+//
 // Rounding bound of the contraction: bf16 keeps 8 significant bits, round-to-nearest errs by <= 2^-8 relative, a
 // product of two rounded factors by <= 2^-7 + 2^-16, and sum_i |a_i b_i| <= |a||b| <= B (B = the largest |q||c| of the
 // call), so |bf16 dot - exact| <= 0.00783 B; the fp32 accumulation of <= 256 products adds < 2e-5 B.  The host
@@ -62,9 +79,13 @@ __global__ void k_df_sample(const int64_t *rowptr, const int32_t *idx, int64_t n
 // k_head_pack: one wave per row of a CSR batch -> its row of W, its tail ratio |x_T| / |x| (the scale of the sparse
 // filter's shard rule), and (store rows) the entry-wise term array the index build reads, head entries masked out.
 // element offset of (row, chunk) in a tiled W of width kh
+// (kh: the TOTAL width of a W row -- 64 | 128 | 256, or 256 B for B blocks; chunk counts across the blocks)
 __host__ __device__ __forceinline__ int64_t head_chunk_off(int64_t row, int chunk, int kh) {
   return (((row >> 6) * (kh / 8) + chunk) * kHeadCTile + (row & 63)) * 8;
 }
+constexpr int kHeadBlock = 256;      // columns per block of a two-block head
+constexpr int kHeadMaxBlocks = 2;    // block 0: one column per term; block 1: the further terms folded into 256 columns
+constexpr int kHeadMaxFold = 31;     // terms per column of the folded block at most: heads of up to 256 * 32 = 8192 terms
 
 struct HeadPackArgs {
   const int64_t *rowptr;   // absolute offsets into idx / val
@@ -72,7 +93,8 @@ struct HeadPackArgs {
   const float *val;
   int64_t row0, row1;      // rows [row0, row1) of that CSR are packed; W rows [w_row0 + row1 - row0, w_pad) are zeroed
   const int32_t *head_pos; // [dim] position of a term in the dense block, -1 = tail term
-  int32_t kh;              // 64 | 128 | 256
+  int32_t kh;              // total width of a W row: 64 | 128 | 256, or 512 (two blocks of 256, each scaled by its own norm; several
+                           // terms may share a column of the second: head_pos maps them to the same position, their values add)
   uint16_t *W;             // tiled; CSR row r lands in W row w_row0 + r - row0
   int64_t w_row0, w_pad;   // w_pad: a multiple of 64 (the GEMM reads whole tiles)
   float *ratio_t;          // [..] |x_T| / |x| per row, indexed like the W rows
@@ -86,7 +108,7 @@ struct HeadPackArgs {
 
 // one wave per W row, 8 rows (one 128-B line per chunk) per workgroup; the workgroup covers W rows [8 g, 8 g + 8)
 __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t rowbuf[8][256];
+  __shared__ __attribute__((aligned(16))) float rowbuf[8][kHeadBlock * kHeadMaxBlocks];  // fp32: a folded column is a sum
   __shared__ unsigned int nz;
   if (threadIdx.x == 0) nz = 0;
   __syncthreads();
@@ -95,10 +117,10 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
   const int64_t wr = g0 + wv;
   const int64_t row = a.row0 + (wr - a.w_row0);         // CSR row of this wave
   const bool real = wr >= a.w_row0 && row < a.row1;
-  for (int i = lane; i < a.kh; i += kWave) rowbuf[wv][i] = 0;
+  for (int i = lane; i < a.kh; i += kWave) rowbuf[wv][i] = 0.f;
   if (real) {
     const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
-    float full2 = 0.f, h2 = 0.f, t2 = 0.f;
+    float full2 = 0.f, t2 = 0.f, h2b[kHeadMaxBlocks] = {0.f, 0.f};
     const float inv = a.row_inv ? a.row_inv[row] : 1.0f;
     for (int64_t k = b + lane; k < e; k += kWave) {
       const float v = a.val[k] * inv;
@@ -107,19 +129,33 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
       if (a.idx_tail) a.idx_tail[k] = hp >= 0 ? (int32_t)kNoTerm : t;
       if (!(v > a.prune_above)) continue;
       full2 += v * v;
-      if (hp >= 0) h2 += v * v; else t2 += v * v;
+      if (hp < 0) t2 += v * v;
+#pragma unroll
+      for (int j = 0; j < kHeadMaxBlocks; ++j) h2b[j] += (hp >= 0 && (hp >> 8) == j) ? v * v : 0.f;  // block of a term: position / 256
     }
     for (int o = kWave / 2; o; o >>= 1) {
       full2 += __shfl_xor(full2, o);
-      h2 += __shfl_xor(h2, o);
       t2 += __shfl_xor(t2, o);
+#pragma unroll
+      for (int j = 0; j < kHeadMaxBlocks; ++j) h2b[j] += __shfl_xor(h2b[j], o);
     }
-    const float scale = h2 > 0.f ? sqrtf(full2 / h2) : 0.f;
+    float scale[kHeadMaxBlocks];
+    float h2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kHeadMaxBlocks; ++j) {
+      scale[j] = h2b[j] > 0.f ? sqrtf(full2 / h2b[j]) : 0.f;  // every block is normalised by ITS norm: w^b = x_{H_b} |x| / |x_{H_b}|
+      h2 += h2b[j];
+    }
     // (LDS operations of one wave execute in order: the zero fill above lands before these entries)
     for (int64_t k = b + lane; k < e; k += kWave) {
       const int32_t hp = a.head_pos[a.idx[k]];
       const float v = a.val[k] * inv;
-      if (hp >= 0 && v > a.prune_above) rowbuf[wv][hp] = f32_to_bf16_rn(v * scale);
+      if (hp >= 0 && v > a.prune_above) {
+        // (block 0: a column belongs to one term, a plain store; block 1: the terms of a column ADD -- |x_{H_2}| above is the
+        // norm of the entries themselves, not of the folded row)
+        if (hp < kHeadBlock) rowbuf[wv][hp] = v * scale[0];
+        else atomicAdd(&rowbuf[wv][hp], v * scale[1]);
+      }
     }
     if (lane == 0) {
       // rounded DOWN a hair: the sparse filter divides the row's tail weights by it (errs on the side of reporting more)
@@ -133,8 +169,15 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
   for (int u = threadIdx.x; u < cpr * 8; u += blockDim.x) {
     const int c = u >> 3, j = u & 7;
     const int64_t w = g0 + j;
-    if (w >= a.w_row0 && w < a.w_pad)
-      *reinterpret_cast<uint4 *>(a.W + head_chunk_off(w, c, a.kh)) = *reinterpret_cast<const uint4 *>(&rowbuf[j][c * 8]);
+    if (w >= a.w_row0 && w < a.w_pad) {
+      const float *f = &rowbuf[j][c * 8];
+      uint4 o;
+      o.x = (uint32_t)f32_to_bf16_rn(f[0]) | (uint32_t)f32_to_bf16_rn(f[1]) << 16;
+      o.y = (uint32_t)f32_to_bf16_rn(f[2]) | (uint32_t)f32_to_bf16_rn(f[3]) << 16;
+      o.z = (uint32_t)f32_to_bf16_rn(f[4]) | (uint32_t)f32_to_bf16_rn(f[5]) << 16;
+      o.w = (uint32_t)f32_to_bf16_rn(f[6]) | (uint32_t)f32_to_bf16_rn(f[7]) << 16;
+      *reinterpret_cast<uint4 *>(a.W + head_chunk_off(w, c, a.kh)) = o;
+    }
   }
   if (threadIdx.x == 0 && nz && a.head_nonempty) atomicAdd(a.head_nonempty, nz);
 }
@@ -175,6 +218,7 @@ struct HeadGemmArgs {
   int32_t n_qblocks, n_panels, n_ctiles;  // n_ctiles: candidate tiles of head_tile_rows(KH) rows
   int32_t part, n_parts;  // this launch multiplies the candidate tiles t with t % n_parts == part (the block of a term-sharded
                           // join is cut over the GPUs by candidate row: 64-row tiles dealt round-robin; 0, 1: every tile)
+  int32_t kt, blk;        // total width of a W row (= KH for a single block) and which block of KH terms this launch multiplies
   int64_t qblock0;      // first query block's first slot (a multiple of 512)
   const int64_t *q_ext, *c_ext;
   float thr;
@@ -232,7 +276,8 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
     const int64_t row = s - qs0;
     const bool ok = row >= 0 && row < a.nq && s < a.wq_rows;
     wave_live |= ok;
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq) + ((ok ? wslot0 : 0) / kHeadCTile) * (CPR * kHeadCTile) + 32 * m + r;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq) + ((ok ? wslot0 : 0) / kHeadCTile) * (int64_t)(a.kt / 8 * kHeadCTile) +
+                       (int64_t)a.blk * (CPR * kHeadCTile) + 32 * m + r;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -245,7 +290,8 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
   // ---- tile copy by LDS-DMA: a tile is TILEB contiguous bytes in HBM and lands in LDS as it is; wave w moves the
   // 1-KiB pieces (= chunks) w * PPW .. , lane l the 16 bytes of row l ----
   auto copy_tile = [&](const int t, const int buf) {
-    const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * TILEB + ln * 16;
+    const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * ((int64_t)kHeadCTile * a.kt * 2) +
+                                (int64_t)a.blk * TILEB + ln * 16;
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
       __builtin_amdgcn_global_load_lds(
@@ -400,7 +446,8 @@ struct HeadGemvArgs {
   int64_t n_rows;
   int64_t q_slot_base;
   int32_t nq;
-  int32_t kh;
+  int32_t kh;             // width of the block this launch multiplies (<= 256)
+  int32_t kt, blk;        // total width of a W row, block index (as in HeadGemmArgs)
   int32_t part, n_parts;  // as in HeadGemmArgs
   const int64_t *q_ext, *c_ext;
   float thr;
@@ -427,7 +474,7 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
     __syncthreads();
     for (int i = tid; i < nqq * a.kh; i += blockDim.x) {
       const int qq = i / a.kh, k = i % a.kh;
-      const uint16_t b = a.Wq[head_chunk_off(qs0 + q0 + qq, k >> 3, a.kh) + (k & 7)];
+      const uint16_t b = a.Wq[head_chunk_off(qs0 + q0 + qq, a.blk * (kHeadBlock / 8) + (k >> 3), a.kt) + (k & 7)];
       qv[qq][k] = __uint_as_float((uint32_t)b << 16);
     }
     __syncthreads();
@@ -437,7 +484,7 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
       float s[kGemvQ];
 #pragma unroll
       for (int qq = 0; qq < kGemvQ; ++qq) s[qq] = 0.f;
-      const uint4 *tp = reinterpret_cast<const uint4 *>(a.Wc) + t * (cpr * kHeadCTile) + ln;
+      const uint4 *tp = reinterpret_cast<const uint4 *>(a.Wc) + t * (int64_t)(a.kt / 8 * kHeadCTile) + (int64_t)a.blk * (kHeadBlock / 8 * kHeadCTile) + ln;
       for (int ch = 0; ch < cpr; ++ch) {
         const uint4 v = tp[ch * kHeadCTile];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};

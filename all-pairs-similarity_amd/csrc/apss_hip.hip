@@ -136,6 +136,8 @@ struct apss_handle {
     DevBuf<Posting> post;
     DevBuf<uint32_t> post_c;
     DevBuf<int64_t> base, total;
+    DevBuf<uint32_t> maxlen;   // [1] longest (tile, term) segment over the builds since the rendering was last started from tile 0
+    uint32_t max_seg = 0;      // its host copy
     std::vector<int64_t> h_base;
     double build_ms = 0;
   };
@@ -172,6 +174,8 @@ struct apss_handle {
   // dense-head block (apss_head.hpp): the KH most frequent terms live in W instead of the inverted index
   int32_t head_k = 0;                 // 0: no block
   bool head_fixed = false;            // the block's terms were set through apss_set_head_terms: no policy, kept across apss_clear
+  bool head_longseg = false;          // term shard with a block: its tail still has segments too long for the thin-round kernel (a
+                                      // hint kept across apss_clear: the next first build goes straight to the layout that serves them)
   int32_t head_part = 0, head_parts = 1;  // this handle multiplies the candidate tiles t % head_parts == head_part of the block
   int64_t head_eval_rows = 0;         // store size when the head policy last looked at the term distribution
   bool head_blocked = false;          // a call needed the plain path: no block until the next apss_clear
@@ -429,6 +433,8 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   APSS_TRY(ensure(h, ix.seg, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
   APSS_TRY(ensure(h, ix.base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
   APSS_TRY(ensure(h, ix.total, (size_t)n_tiles, 0));
+  APSS_TRY(ensure(h, ix.maxlen, 1));
+  if (tile0 == 0) HIPCHK(h, hipMemsetAsync(ix.maxlen.p, 0, sizeof(uint32_t), h->stream));
   DevBuf<float> &tmin = ix.coarse ? h->tile_min_c : h->tile_min;
   const bool scaled = h->sharded || h->head_k > 0;  // the probe scales its threshold per query and tile (shard rule)
   if (scaled) APSS_TRY(ensure(h, tmin, (size_t)n_tiles, (size_t)tile0));
@@ -466,11 +472,12 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   if (lds_build) hipLaunchKernelGGL(k_tile_hist_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
   else hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
   hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, ix.seg.p, stride, h->cfg.dim,
-                     tile0, ix.total.p, (uint32_t)ix.align, lds_build ? 1u : 0u);
+                     tile0, ix.total.p, (uint32_t)ix.align, lds_build ? 1u : 0u, ix.maxlen.p);
   HIPCHK(h, hipGetLastError());
   // padded posting counts -> tile bases (host prefix sum: a handful of values), then reserve the posting array
   std::vector<int64_t> tot((size_t)(n_tiles - tile0));
   HIPCHK(h, hipMemcpyAsync(tot.data(), ix.total.p + tile0, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&ix.max_seg, ix.maxlen.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (size_t i = 0; i < tot.size(); ++i) ix.h_base.push_back(ix.h_base.back() + tot[i]);
   HIPCHK(h, hipMemcpyAsync(ix.base.p + tile0, ix.h_base.data() + tile0, (size_t)(n_tiles - tile0 + 1) * sizeof(int64_t),
@@ -527,12 +534,18 @@ double acc8_scale(double bound, double shared, double theta) {
 constexpr int64_t kTailMaxRows = 4096;   // rows that may wait outside the tile index (scored pair by pair by k_tail_score)
 constexpr int64_t kTailMaxBatch = 256;   // a batch larger than this extends the index right away
 constexpr int64_t kTailMaxPairs = 1 << 22;  // (queries x tail rows) a probe scores directly; beyond it the tail is folded in first
-constexpr int32_t kHeadMaxTerms = 256;   // widest block (k_head_gemm<256>)
+constexpr int32_t kHeadMaxTerms = kHeadBlock * (1 + kHeadMaxFold);   // 256 terms with a column each + 256 columns of kHeadMaxFold terms
+inline int32_t head_width(int32_t n_terms) {  // width of a W row holding n_terms head terms
+  return n_terms <= 64 ? 64 : (n_terms <= 128 ? 128 : (n_terms <= 256 ? 256 : 512));
+}
+// column of the i-th head term (most frequent first): the first 256 get a column each, the others fold into the second block
+inline int32_t head_column(int32_t i) { return i < kHeadBlock ? i : kHeadBlock + (i - kHeadBlock) % kHeadBlock; }
 constexpr int64_t kHeadMinRows = 16384;  // below this a join is over before a GEMM pays for its set-up
 constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse filter (measured, C3)
 // seconds per (query, candidate) element of the head contraction, block width 64 / 128 / 256 (measured on random rows,
 // profiles/r02_head_gemm.md: 1.65 PFLOP/s at 256; narrower blocks are bound by the epilogue's scan, not by the MFMAs)
-constexpr double kHeadDenseCost[3] = {1.5e-13, 1.9e-13, 3.1e-13};
+constexpr double kHeadDenseCost[4] = {1.5e-13, 1.9e-13, 3.1e-13, 6.2e-13};  // (last: two blocks of 256 = 256 terms + a folded block)
+constexpr double kHeadFoldMaxRowTerms = 64.0;  // terms of the folded block a row may hold on average (chance pairs collide in m^2 / 256 columns)
 constexpr double kHeadSurvivorCost = 1.0e-8;  // seconds per element the dense filter passes on (report + de-dup + exact re-score)
 
 // A plain handle decides for itself (choose_head) unless the block's terms were set through apss_set_head_terms; a term
@@ -662,24 +675,31 @@ int32_t choose_head(apss_handle *h, bool *changed) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   std::vector<int32_t> order((size_t)dim);
   for (int32_t t = 0; t < dim; ++t) order[(size_t)t] = t;
-  const size_t top = (size_t)std::min<int32_t>(dim, 256);
+  const size_t top = (size_t)std::min<int32_t>(dim, kHeadMaxTerms);
   std::partial_sort(order.begin(), order.begin() + (ptrdiff_t)top, order.end(),
                     [&](int32_t x, int32_t y) { return df[(size_t)x] != df[(size_t)y] ? df[(size_t)x] > df[(size_t)y] : x < y; });
   int32_t k = 0;
   double best_gain = 0.0;  // seconds per N^2 pairs the chosen block is expected to save
+  double gain256 = 0.0;    // ... and a plain 256-term block, the fall-back when the folded block proves unselective
   if (h->cfg.head_terms > 0) {
-    k = h->cfg.head_terms <= 64 ? 64 : (h->cfg.head_terms <= 128 ? 128 : 256);
+    k = std::min(h->cfg.head_terms <= 256 ? head_width(h->cfg.head_terms) : h->cfg.head_terms, kHeadMaxTerms);  // terms wanted
   } else if (n >= kHeadMinRows) {
     double best = 0.0, s2 = 0.0;
     size_t i = 0;
     int ki = 0;
-    for (int32_t kk : {64, 128, 256}) {
+    double m_fold = 0.0;  // average number of folded-block terms per row
+    for (int32_t kk : {64, 128, 256, 512, 1024, 2048, 4096, 8192}) {
+      if (kk > kHeadMaxTerms || (size_t)kk > top + 255) break;
       for (; i < std::min<size_t>(top, (size_t)kk); ++i) {
         const double f = (double)df[(size_t)order[i]] / (double)sampled;
         s2 += f * f;
+        if (i >= (size_t)kHeadBlock) m_fold += f;
       }
-      // per N^2 pairs of a stored batch: df_t^2 = f_t^2 N^2 visits saved; half of the product computed (symmetric)
-      const double save = s2 / kHeadSparseRate, cost = 0.5 * kHeadDenseCost[ki++];
+      if (m_fold > kHeadFoldMaxRowTerms) break;
+      // per N^2 pairs of a stored batch: df_t^2 = f_t^2 N^2 visits saved; half of the product computed (symmetric).  A head
+      // of more than 256 terms costs ONE more contraction however many terms fold into it
+      const double save = s2 / kHeadSparseRate, cost = 0.5 * kHeadDenseCost[std::min(ki++, 3)];
+      if (save >= 1.5 * cost && kk == kHeadBlock) gain256 = save - cost;
       if (save >= 1.5 * cost && save - cost > best) {
         best = save - cost;
         k = kk;
@@ -687,34 +707,40 @@ int32_t choose_head(apss_handle *h, bool *changed) {
     }
     best_gain = best;
   }
-  if (k > dim) k = 0;
+  if (std::min(k, kHeadBlock) > dim) k = 0;
   std::vector<int32_t> terms;
   for (size_t i = 0; i < std::min<size_t>(top, (size_t)k); ++i)
     if (df[(size_t)order[i]] > 0) terms.push_back(order[i]);
-  if (terms.empty()) k = 0;
   const int32_t old_k = h->head_k;
   const std::vector<int32_t> old_terms = h->head_terms;
-  const bool differs = k != old_k || terms != old_terms;
-  h->head_k = k;
-  h->head_terms = terms;
-  if (k && differs) {
-    std::vector<int32_t> pos((size_t)dim, -1);
-    for (size_t i = 0; i < terms.size(); ++i) pos[(size_t)terms[i]] = (int32_t)i;
-    APSS_TRY(ensure(h, h->head_pos, (size_t)dim));
-    HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // `pos` goes out of scope
-  }
-  if (k && differs && h->cfg.head_terms == 0) {  // (a block that is already in use has passed this test)
+  for (;;) {
+    k = terms.empty() ? 0 : head_width((int32_t)terms.size());  // from here on: the width of a W row
+    const bool differs = k != old_k || terms != old_terms;
+    h->head_k = k;
+    h->head_terms = terms;
+    if (k && differs) {
+      std::vector<int32_t> pos((size_t)dim, -1);
+      for (size_t i = 0; i < terms.size(); ++i) pos[(size_t)terms[i]] = head_column((int32_t)i);
+      APSS_TRY(ensure(h, h->head_pos, (size_t)dim));
+      HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));  // `pos` goes out of scope
+    }
+    if (!(k && differs && h->cfg.head_terms == 0)) break;  // (a block that is already in use has passed the test below)
     // the visit count says yes; now the other side of the ledger: every element the dense filter passes is reported,
     // de-duplicated and re-scored (measured: ~10 ns each).  At a low threshold on strongly skewed data that can be a
     // fraction of a percent of N^2 -- more than the posting visits saved (C2: theta = 0.5).  Measure it on a sample.
     double frac = 0.0;
     APSS_TRY(head_sample_selectivity(h, &frac));
     h->head_sample_frac = frac;
-    if (frac * kHeadSurvivorCost > 0.5 * best_gain) {
-      h->head_k = 0;
-      h->head_terms.clear();
+    if (frac * kHeadSurvivorCost <= 0.5 * best_gain) break;
+    if (terms.size() > (size_t)kHeadBlock && gain256 > 0.0) {  // the folded block passes too much here: try the 256 terms alone
+      terms.resize((size_t)kHeadBlock);
+      best_gain = gain256;
+      continue;
     }
+    h->head_k = 0;
+    h->head_terms.clear();
+    break;
   }
   *changed = h->head_k != old_k || h->head_terms != old_terms;
   return APSS_OK;
@@ -735,7 +761,7 @@ int32_t build_index(apss_handle *h, int64_t row0) {
       }
     }
     if (h->head_k) {
-      h->cx.cb = std::min(h->cx.cb, 32768);  // the sparse half runs the 512-thread shard-rule kernel
+      h->cx.cb = std::min(h->cx.cb, 65536);  // the sparse half runs a 512-thread shard-rule kernel
       if (h->sharded) APSS_TRY(head_mask_store(h, row0, row0 ? h->idx_tail_valid : 0));  // (W and the ratios: ingest)
       else APSS_TRY(head_pack_store(h, row0));
     }
@@ -764,12 +790,25 @@ int32_t build_index(apss_handle *h, int64_t row0) {
         h->cx.cb = 131072;
       // a term shard's rounds are thin (1/T of every query's terms): 8-bit accumulators hold 65536 candidates in the same
       // 64 KB, i.e. half the rounds at the same two workgroups per CU -- when the norms and row lengths leave room for them
-      if (h->sharded && !h->head_k && !h->dbgcfg.no_acc8 && !h->no_acc8 &&
+      // (with a dense-head block: only while the tail has no long segments -- the prefetched long-segment sweeps exist for
+      // 16-bit accumulators over 32768-row tiles only; known after the build, so an optimistic first build may be repeated)
+      if ((h->sharded || h->head_k) && !(h->head_k && h->head_longseg) && !h->dbgcfg.no_acc8 && !h->no_acc8 &&
           acc8_scale((double)h->store_max_norm2 * 1.0001 + 1e-6, (double)h->store_max_nnz, h->cfg.theta) > 0)
         h->cx.cb = 65536;
     }
     APSS_TRY(build_tiles(h, h->cx, row0));
     h->st.build_ms += h->cx.build_ms;
+    if (h->head_k && h->cfg.tile_rows == 0 && !h->dbgcfg.cx_tile) {
+      if (h->cx.cb > 32768 && h->cx.max_seg > (uint32_t)kLongLenW) {
+        h->head_longseg = true;
+        h->cx.cb = 32768;
+        h->cx.n_tiles = 0;
+        APSS_TRY(build_tiles(h, h->cx, 0));
+        h->st.build_ms += h->cx.build_ms;
+      } else if (h->cx.cb <= 32768 && h->head_longseg && row0 == 0 && 2 * h->cx.max_seg <= (uint32_t)kLongLenW) {
+        h->head_longseg = false;  // (this data would have fitted: the next first build tries the wide tiles again)
+      }
+    }
     h->ex_built_rows = std::min(h->ex_built_rows, row0 / h->ex.cb * h->ex.cb);  // exact tiles from here on are stale
   } else {
     h->ex_built_rows = std::min(h->ex_built_rows, row0);
@@ -913,7 +952,9 @@ int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
 // ---- dense-head filter of one query batch (apss_head.hpp): appends its candidates to the sparse filter's list ----
 int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_base, const uint16_t *Wq, int64_t wq_rows,
                  float thr, int64_t n_cand) {
-  const int kh = h->head_k;
+  const int kt = h->head_k;                        // width of a W row
+  const int kh = std::min(kt, kHeadBlock);        // width of one block = of one contraction
+  const int n_blocks = std::max(1, kt / kHeadBlock);
   if (nq <= 2 * kGemvQ) {
     HeadGemvArgs g{};
     g.Wq = Wq;
@@ -922,6 +963,7 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
     g.q_slot_base = q_slot_base;
     g.nq = (int32_t)nq;
     g.kh = kh;
+    g.kt = kt;
     g.part = h->head_part;
     g.n_parts = h->head_parts;
     g.q_ext = a.q_ext;
@@ -934,9 +976,13 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
     g.counters = a.counters;
     g.head_pairs = h->head_ctr.p + 1;
     const int64_t blocks = std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div(n_cand, 256 * (int64_t)h->head_parts)));
-    hipLaunchKernelGGL(k_head_gemv, dim3((unsigned)blocks), dim3(256), 0, h->stream, g);
+    for (int b = 0; b < n_blocks; ++b) {
+      g.blk = b;
+      g.head_pairs = h->head_ctr.p + (b == 0 ? 1 : 3);  // (pairs sharing a term of the FIRST block: the statistic; the others' counts are dropped)
+      hipLaunchKernelGGL(k_head_gemv, dim3((unsigned)blocks), dim3(256), 0, h->stream, g);
+    }
     HIPCHK(h, hipGetLastError());
-    h->st.head_flops = 2.0 * kh * (double)nq * (double)n_cand / (double)h->head_parts;
+    h->st.head_flops = 2.0 * kt * (double)nq * (double)n_cand / (double)h->head_parts;
     return APSS_OK;
   }
   HeadGemmArgs g{};
@@ -970,9 +1016,15 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
   g.counters = a.counters;
   g.head_pairs = h->head_ctr.p + 1;
   const dim3 grid((unsigned)((int64_t)g.n_qblocks * g.n_panels));
+  g.kt = kt;
+  g.blk = 0;
   if (kh == 64) hipLaunchKernelGGL(k_head_gemm<64>, grid, dim3(512), 0, h->stream, g);
   else if (kh == 128) hipLaunchKernelGGL(k_head_gemm<128>, grid, dim3(512), 0, h->stream, g);
   else hipLaunchKernelGGL(k_head_gemm<256>, grid, dim3(512), 0, h->stream, g);
+  for (int b = 1; b < n_blocks; ++b) {  // the further blocks of a wide head: the same contraction over the next 256 terms, no pair statistic
+    g.blk = b;
+    hipLaunchKernelGGL((k_head_gemm<256, false>), grid, dim3(512), 0, h->stream, g);
+  }
   HIPCHK(h, hipGetLastError());
   // multiplied elements: every (query block, candidate tile) the grid does not skip, at MFMA granularity
   double tiles = 0;
@@ -980,7 +1032,7 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
     const int64_t hi = q_slot_base >= 0 ? std::min<int64_t>(g.n_ctiles, (g.qblock0 + (b + 1) * kHeadQBlock) / ct) : g.n_ctiles;
     tiles += hi > g.part ? (double)ceil_div(hi - g.part, g.n_parts) : 0.0;  // the tiles t < hi with t % n_parts == part
   }
-  h->st.head_flops = 2.0 * kh * tiles * (double)ct * (double)kHeadQBlock;
+  h->st.head_flops = 2.0 * kt * tiles * (double)ct * (double)kHeadQBlock;
   return APSS_OK;
 }
 
@@ -1051,12 +1103,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
                          (h->cx.cb <= 32768 || q_max_nnz <= 512) && !dbg.chunk8 && !dbg.window;
   // 65536-row tiles (term shards; the sparse regime of a plain handle): the 8-bit filter -- 65536 candidates in 64 KB, two
   // 512-thread workgroups per CU -- if this call's norms and row lengths leave room for its sums
-  const bool big_shard_tiles = h->sharded && h->cx.cb > 32768;
-  const double a8_scale = h->cx.cb >= 65536 && mode == 0 && !h->head_k && q_max_nnz <= 512 && !dbg.no_acc8 && !h->no_acc8 && !dbg.chunk8
+  const bool big_shard_tiles = shard_rule && h->cx.cb > 32768;
+  const double a8_scale = h->cx.cb >= 65536 && mode == 0 && q_max_nnz <= 512 && !dbg.no_acc8 && !h->no_acc8 && !dbg.chunk8
                               ? acc8_scale(bound, cx_shared, theta) : 0.0;
   if ((big_shard_tiles || h->cx.cb > 65536) && !(a8_scale > 0)) {
     // not this time (a long row, a large norm, signed weights): back to 16-bit accumulators over smaller tiles, for good
-    h->cx.cb = h->sharded ? 32768 : 65536;
+    h->cx.cb = shard_rule ? 32768 : 65536;
     h->cx.n_tiles = 0;
     h->no_acc8 = true;
     h->downgrades |= APSS_DOWNGRADE_ACC8;
@@ -1171,7 +1223,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     if (cxv.vrows || cxv.sgn) u = cxv.block == 1024 ? u : 5;
     if (dbg.chunk8) u = 4;
     if (dbg.window && cxv.block == 512 && !cxv.vrows && !cxv.sgn) u = dbg.window;
-    if (hybrid_wanted && !dbg.window) {  // the skewed tail of a handle with a dense-head block: full window, prefetched long sweeps
+    // the skewed tail of a handle with a dense-head block: full window, prefetched long sweeps.  (A term shard's tail range
+    // may hold no long segment at all once the block has taken the frequent terms: it then runs like any other shard)
+    const bool long_tail = hybrid_wanted && h->cx.max_seg > (uint32_t)kLongLenW && !cxv.acc8;
+    if (long_tail && !dbg.window) {
       u = 5;
       cxv.longpf = true;
     }
@@ -1386,7 +1441,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       // the 8-bit filter turned out unselective on this data (skewed terms: chance pairs share dozens of them, and every
       // shared term adds its unit of round-up): correct, but the survivors would swamp the exact pass.  Back to 16-bit
       // accumulators, for good, and run the call again.
-      h->cx.cb = h->sharded ? 32768 : 65536;
+      h->cx.cb = shard_rule ? 32768 : 65536;
       h->cx.n_tiles = 0;
       h->no_acc8 = true;
       h->downgrades |= APSS_DOWNGRADE_ACC8;
@@ -1723,7 +1778,7 @@ void apss_destroy(apss_handle *h) {
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   release(h->rowptr); release(h->ext); release(h->idx); release(h->erow); release(h->val); release(h->sub);
-  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); }
+  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); release(s->maxlen); }
   release(h->tile_min); release(h->tile_min_c); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst); release(h->scan_tmp);
@@ -1906,7 +1961,7 @@ int32_t apss_clear(apss_handle *h) {
 int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *terms, int32_t part, int32_t n_parts) {
   APSS_TRY(enter(h));
   if (h->n_rows != 0) return fail(h, APSS_E_STATE, "apss_set_head_terms: the handle holds vectors (set the block before the first insert or after apss_clear)");
-  if (n_terms < 0 || n_terms > kHeadMaxTerms || (n_terms > 0 && !terms)) return fail(h, APSS_E_INVALID, "apss_set_head_terms: 0 .. 256 terms");
+  if (n_terms < 0 || n_terms > kHeadMaxTerms || (n_terms > 0 && !terms)) return fail(h, APSS_E_INVALID, "apss_set_head_terms: 0 .. 8192 terms");
   if (n_parts < 1 || part < 0 || part >= n_parts) return fail(h, APSS_E_INVALID, "apss_set_head_terms: part must be in [0, n_parts)");
   if (n_parts > 1 && !h->sharded)
     return fail(h, APSS_E_INVALID, "apss_set_head_terms: only a term shard multiplies a share of the block (n_parts > 1)");
@@ -1926,13 +1981,13 @@ int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *term
   for (int32_t i = 0; i < n_terms; ++i) {
     if (terms[i] < 0 || terms[i] >= h->cfg.dim || pos[(size_t)terms[i]] >= 0)
       return fail(h, APSS_E_INVALID, "apss_set_head_terms: terms must be distinct and in [0, dim)");
-    pos[(size_t)terms[i]] = i;
+    pos[(size_t)terms[i]] = head_column(i);
   }
   APSS_TRY(ensure(h, h->head_pos, (size_t)h->cfg.dim));
   HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)h->cfg.dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->head_terms.assign(terms, terms + n_terms);
-  h->head_k = n_terms <= 64 ? 64 : (n_terms <= 128 ? 128 : 256);
+  h->head_k = head_width(n_terms);
   h->head_fixed = true;
   h->head_blocked = false;
   h->head_part = part;

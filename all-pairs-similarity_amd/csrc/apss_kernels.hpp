@@ -364,13 +364,13 @@ __global__ void k_tile_hist(BuildArgs a) {
 
 // one workgroup per tile: exclusive scan of the aligned lengths; tile_total[tile] = postings incl. padding
 __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0,
-                                                    int64_t *tile_total, uint32_t align, uint32_t keep_len) {
+                                                    int64_t *tile_total, uint32_t align, uint32_t keep_len, uint32_t *max_len) {
   // one workgroup per tile walks the tile's dim entries in blocks of kScanBlock, four CONSECUTIVE entries per thread (a
   // strided stream per thread took 4.2 ms per build at dim = 2^20, 16 tiles)
   __shared__ uint32_t wave_tot[17];
   uint2 *sg = tile_seg + (tile0 + blockIdx.x) * seg_stride;
   const int tid = threadIdx.x;
-  uint32_t carry = 0;
+  uint32_t carry = 0, longest = 0;
   for (int32_t base = 0; base < dim; base += kScanBlock) {
     const int32_t i0 = base + tid * 4;
     uint32_t len[4], s = 0;
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
     for (int k = 0; k < 4; ++k) {
       len[k] = i0 + k < dim ? sg[i0 + k].y : 0u;
       s += (len[k] + align - 1) / align * align;
+      longest = max(longest, len[k]);
     }
     uint32_t total;
     uint32_t run = carry + block_excl_scan_1024<uint32_t>(s, wave_tot, &total);
@@ -391,6 +392,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
     __syncthreads();  // (wave_tot is reused by the next block)
   }
   if (tid == 0) tile_total[tile0 + blockIdx.x] = carry;
+  // the longest (tile, term) segment of the build: tells the probe whether its long-segment machinery is needed at all
+  for (int o = kWave / 2; o; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+  if (max_len && (tid % kWave) == 0 && longest) atomicMax(max_len, longest);
 }
 
 __global__ void k_tile_scatter(BuildArgs a) {

@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--rows", "--n", dest="n", type=int, default=None, help="override the number of vectors (debug); "
                     "spell it --rows under torch.distributed.run, whose own parser claims every prefix of its options")
     ap.add_argument("--tile-rows", type=int, default=0)
-    ap.add_argument("--head-terms", type=int, default=0, help="dense-head block: 0 auto, -1 never, 64 | 128 | 256")
+    ap.add_argument("--head-terms", type=int, default=0, help="dense-head block: 0 auto, -1 never, 64 | 128 | 256 | 512 | 1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-row", action="store_true", help="skip the fp32-accumulate sibling measurement")
     ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid of the headline layout (default: all ranks)")
@@ -229,7 +229,8 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
                     "head_survivors": st["head_survivors"],
                     "candidate_pairs_note": "max(pairs sharing a tail term, pairs sharing a head term): a lower bound of "
                                             "the distinct pairs scored (a pair sharing both kinds is scored by both filters)"})
-        head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d> (v_mfma_f32_32x32x16_bf16)" % st["head_terms"],
+        head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16)" % (
+                         min(256, st["head_terms"]), " x %d blocks" % ((st["head_terms"] + 255) // 256) if st["head_terms"] > 256 else ""),
                      "achieved": flops / head_s / 1e12 if head_s > 0 else None, "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / head_s / 1e12 / MFMA_BF16_PEAK_TFLOPS if head_s > 0 else None,
                      "traffic": None,
@@ -328,8 +329,10 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
         row["roofline"] = sparse_roof
         if sj.last.get("head_terms") and hm > 0:
             # skewed terms: the join's dense-head block, cut over the term group's ranks by candidate tile (apss/dist.py)
-            kh = 64 if sj.last["head_terms"] <= 64 else (128 if sj.last["head_terms"] <= 128 else 256)
-            head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d> (v_mfma_f32_32x32x16_bf16), candidate tiles t %% %d == rank" % (kh, sj.T),
+            nt = sj.last["head_terms"]
+            kh = 64 if nt <= 64 else (128 if nt <= 128 else 256)
+            head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16), candidate tiles t %% %d == rank" % (
+                             kh, " x %d blocks" % ((nt + 255) // 256) if nt > 256 else "", sj.T),
                          "achieved": head_flops / (hm * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s (per GPU: the slowest rank's kernel and that rank's flops)",
                          "frac": head_flops / (hm * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None}
@@ -418,8 +421,16 @@ def main():
         from apss.dist import HipShardEngine, term_ranges
         wd.phase = "solo shard"
         T, D, ti, dj = (int(x) for x in a.solo.split(","))
-        tr = term_ranges(np.bincount(idx, minlength=cfg["dim"]), T)[ti]
-        eng = HipShardEngine(cfg["dim"], cfg["theta"], tr, dev, a.tile_rows)
+        df = np.bincount(idx, minlength=cfg["dim"])
+        head = None
+        if T > 1 and a.head_terms >= 0:  # what rank 0 of the sharded join decides and broadcasts (apss/dist.py)
+            from apss.dist import hip_head_chooser
+            terms = hip_head_chooser(cfg["dim"], cfg["theta"], dev, a.head_terms)(rp, idx, val)
+            if terms.size:
+                head = (terms, ti, T)
+                df[terms] = 0
+        tr = term_ranges(df, T)[ti]
+        eng = HipShardEngine(cfg["dim"], cfg["theta"], tr, dev, a.tile_rows, head)
         eng.load(rp, idx, val, None if D == 1 else (n * dj // D, n * (dj + 1) // D))
         step = eng.join if T == 1 else (lambda: int(eng.candidates()[0].numel()))  # term shards hand their candidates on
         step()
@@ -431,7 +442,10 @@ def main():
         dt = (time.perf_counter() - t0) / a.steps
         print(json.dumps({"solo_shard": a.solo, "ms_per_step": dt * 1e3, "probe_kernel_ms": eng.stats["probe_ms"],
                           "build_ms": eng.stats["build_ms"], "posting_visits": eng.stats["posting_visits"],
-                          "candidates": int(n_c),
+                          "candidates": int(n_c), "probe_kernel": eng.stats["probe_kernel"], "head_terms": eng.stats["head_terms"],
+                          "head_ms": eng.stats["head_ms"], "head_survivors": eng.stats["head_survivors"],
+                          "head_frac_of_bf16_peak": (eng.stats["head_flops"] / (eng.stats["head_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
+                                                     if eng.stats["head_ms"] > 0 else None),
                           "algorithmic_frac": BYTES_PER_VISIT * eng.stats["posting_visits"] / (eng.stats["probe_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}))
         wd.done()
         return

@@ -70,7 +70,8 @@ typedef struct apss_config {
                               library may pick 65536 (sparse regime, term shards with 8-bit accumulators) or 131072 rows
                               (sparser still) from the data: apss_stats.tiles says what it took */
   int32_t head_terms;      /* dense-head block: 0 = the library decides from the term distribution, -1 = never,
-                              64 | 128 | 256 = always that many of the most frequent terms.  Terms in the block are scored
+                              64 | 128 | 256 | 512 | 1024 = always that many of the most frequent terms (512, 1024: two / four
+                              blocks of 256, each a part of its own under the candidate rule).  Terms in the block are scored
                               by a bf16 MFMA contraction instead of their posting lists; results are the same set */
   int64_t capacity_rows;   /* hints for the initial HBM reservation (0 = grow on demand) */
   int64_t capacity_nnz;
@@ -183,7 +184,7 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
 
 
 /* ---- dense-head block set by the caller ----
- * The `n_terms` (<= 256) most frequent terms are scored by a bf16 MFMA contraction over W = [rows x n_terms] instead of
+ * The `n_terms` (<= 1024; more than 256: blocks of 256 in the order given) most frequent terms are scored by a bf16 MFMA contraction over W = [rows x n_terms] instead of
  * their posting lists (CommonUtils.scala:110-115 restricted to those dims; a FILTER: survivors are re-scored exactly).
  * On a plain handle this replaces the library's own choice (apss_config.head_terms).  On a TERM SHARD it is the only way
  * to get a block: every shard of a join must be given the SAME terms -- they are a part of their own, {H, T_1 .. T_T}, in

@@ -55,7 +55,7 @@ def test_bench_skewed_workload_reports_an_mfma_roofline():
     d = _one_line(out)
     for k in DRIVER_KEYS:
         assert k in d, k
-    assert d["head_terms"] in (64, 128, 256) and d["head_pairs_per_step"] > 0 and "bf16" in d["dtype"]
+    assert d["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and d["head_pairs_per_step"] > 0 and "bf16" in d["dtype"]
     roofs = [d["roofline"]] + [d[k] for k in ("roofline_sparse_filter", "roofline_dense_head") if k in d]
     assert len(roofs) == 2 and {r["bound"] for r in roofs} == {"lds", "mfma"}
     m = [r for r in roofs if r["bound"] == "mfma"][0]
@@ -91,3 +91,25 @@ def test_bench_two_ranks_report_both_layouts():
     comp = d["candidate_range_layout"]
     assert comp["grid"] == "1 term-range shards x 2 candidate ranges" and comp["value"] > 0
     assert comp["result_pairs_per_step"] == d["result_pairs_per_step"]
+
+
+def test_bench_two_ranks_skewed_terms_take_the_dense_head_block():
+    """N = 2 rehearsal (gloo) of C3 with Zipf(1) terms at reduced N -- BASELINE.json configs[4]'s layout: term-range shards
+    AND the dense-head block, rank 0's policy choice broadcast, the block's contraction cut over the two ranks by candidate
+    tile.  The line carries an MFMA roofline per rank next to the sparse filter's, and the candidate-range layout (plain
+    handles that decide for themselves) reports the same result set"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3z1",
+                          "--rows", "50000", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--cpu-seconds", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _one_line(out)
+    for k in DRIVER_KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and d["head_kernel_ms_slowest_rank"] > 0
+    roofs = [d["roofline"]] + [d[k] for k in ("roofline_sparse_filter", "roofline_dense_head") if k in d]
+    assert len(roofs) == 2 and {r["bound"] for r in roofs} == {"lds", "mfma"}
+    m = [r for r in roofs if r["bound"] == "mfma"][0]
+    assert 0 < m["frac"] < 1.0 and "k_head_gemm" in m["kernel"] and "% 2 == rank" in m["kernel"]
+    assert d["candidate_range_layout"]["result_pairs_per_step"] == d["result_pairs_per_step"] > 100

@@ -45,6 +45,35 @@ def test_forced_head_block_matches_oracle(engine, oracle, kh, n, dim, nnz, theta
     assert st0["candidate_pairs"] <= st["candidate_pairs"] + st["head_pairs"] + st0["candidate_pairs"] // 2
 
 
+@pytest.mark.parametrize("kh", [512, 1024, 4096])
+@pytest.mark.parametrize("n,dim,nnz,theta", [(3000, 2048, 24, 0.5), (5000, 10000, 50, 0.6)])
+def test_wide_head_with_a_folded_block_matches_oracle(engine, oracle, kh, n, dim, nnz, theta):
+    """heads of more than 256 terms: the 256 most frequent keep a column each, the others FOLD into a second block of 256
+    columns (term i adds into column i mod 256) whose dot product bounds the true partial score from above (non-negative
+    weights) -- one more contraction whatever the number of terms.  Same pairs as the oracle and as the plain path, fewer
+    posting visits than a 256-term head; dim = 2048 with 4096 wanted: EVERY term is in the head and the join is two GEMMs"""
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=61 + kh, dup_frac=0.1)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 100
+    got, st = _join(engine, dim, theta, rp, idx, val, head_terms=kh, tile_rows=1024)
+    n_used = int((np.bincount(idx, minlength=dim) > 0).sum())
+    assert st["head_terms"] == min(kh, n_used) and st["head_pairs"] > 0
+    assert_same_pairs(got, want, theta)
+    ref, st1 = _join(engine, dim, theta, rp, idx, val, head_terms=256, tile_rows=1024)
+    assert ref.keys() == got.keys() and st["posting_visits"] < st1["posting_visits"]
+    if kh >= dim:
+        assert st["posting_visits"] == 0
+    assert st["head_pairs"] == st1["head_pairs"]  # the statistic counts the first block's pairs
+    assert abs(st["head_flops"] / st1["head_flops"] - 2.0) < 1e-9  # one more contraction of width 256, whatever kh
+    # an outside query batch (square form) and a handful of queries (GEMV form) over both blocks
+    with engine.ApssIndex(dim, theta, head_terms=kh, tile_rows=1024) as ix:
+        ix.insert(np.arange(n), rp, idx, val)
+        for b0, b1 in ((7, 12), (100, 700)):
+            sl = slice(rp[b0], rp[b1])
+            gq = to_map(*ix.query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl]))
+            assert_same_pairs(gq, {k: v for k, v in want.items() if b0 <= k[0] < b1}, theta)
+
+
 def test_head_pairs_count_is_exact(engine):
     """`head_pairs` against an independent count: pairs sharing at least one of the block's terms (scipy boolean X X^T
     restricted to the most frequent terms), self pairs excluded"""
@@ -86,7 +115,7 @@ def test_c3_shape_zipf1_auto_policy(engine, oracle):
     cfg, rp, idx, val = synth.make_config("c3z1", n=60_000, device="cuda")
     dim, theta = cfg["dim"], cfg["theta"]
     got, st = _join(engine, dim, theta, rp, idx, val)
-    assert st["head_terms"] in (64, 128, 256) and st["head_pairs"] > 0, st
+    assert st["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and st["head_pairs"] > 0, st
     ref, st0 = _join(engine, dim, theta, rp, idx, val, head_terms=-1)
     assert st0["head_terms"] == 0 and ref.keys() == got.keys() and len(got) > 1000
     assert st["posting_visits"] < st0["posting_visits"] // 10
@@ -107,7 +136,7 @@ def test_c5_power_law_reduced(engine, oracle):
     with engine.ApssIndex(dim, theta) as ix:
         got = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
         st = ix.stats()
-        assert st["head_terms"] in (64, 128, 256) and st["head_pairs"] > 0.9 * n * (n - 1), st
+        assert st["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and st["head_pairs"] > 0.9 * n * (n - 1), st
         b0, b1 = 5000, 5600
         sl = slice(rp[b0], rp[b1])
         gq = to_map(*ix.query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl]))
