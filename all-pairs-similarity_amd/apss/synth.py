@@ -164,14 +164,27 @@ def stratified_dot(idx, val, a, b, block=1 << 20):
     return out
 
 
-def make_vectors_zipf_dev(n, dim, nnz, zipf_s, seed, device, dup_frac=0.05, block=1 << 16):
+def rows_dot(idx, val, a, b, block=2048):
+    """exact dot products, in float64, of rows a[k], b[k] of a batch with a fixed number of entries per row (idx [n, nnz]
+    ascending per row, val [n, nnz]): every entry of one row against every entry of the other"""
+    import torch
+    out = torch.empty(a.numel(), dtype=torch.float64, device=idx.device)
+    for k0 in range(0, a.numel(), block):
+        x, y = a[k0:k0 + block], b[k0:k0 + block]
+        eq = idx[x][:, :, None] == idx[y][:, None, :]
+        out[k0:k0 + block] = (eq * (val[x].double()[:, :, None] * val[y].double()[:, None, :])).sum(dim=(1, 2))
+    return out
+
+
+def make_vectors_zipf_dev(n, dim, nnz, zipf_s, seed, device, dup_frac=0.05, block=1 << 16, return_src=False):
     """Zipf(s) workload drawn with torch on `device` (the GPU for the million-row configs; "cpu" works for tests).
 
     Per row: 3 * nnz draws with replacement from p_t ~ 1 / rank^s (term ids randomly permuted), the first nnz DISTINCT
     ones in draw order are the row's terms (rows short of nnz distinct draws -- rare -- draw again, 16x as many);
     values |N(0,1)| + 0.05; planted near-duplicates as in make_vectors (10 % of the terms replaced by uniformly drawn
     ones that the row does not hold yet, values x U(0.9, 1.1)); rows L2-normalised (benchmark/LoadGenerator.scala:34-37).
-    Returns torch tensors (rowptr int64[n+1], idx int32[n, nnz] ascending per row, val float32[n, nnz])."""
+    Returns torch tensors (rowptr int64[n+1], idx int32[n, nnz] ascending per row, val float32[n, nnz]); with return_src
+    also src int64[n]: the base row a planted near-duplicate was copied from (-1: a base row)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -205,6 +218,7 @@ def make_vectors_zipf_dev(n, dim, nnz, zipf_s, seed, device, dup_frac=0.05, bloc
             bad = bad[~ok2]
         idx[r0:r0 + m] = torch.sort(perm[out], dim=1).values
     val = torch.randn((n, nnz), generator=g, device=device).abs_() + 0.05
+    src_all = torch.full((n,), -1, dtype=torch.int64, device=device)
 
     if dup_frac > 0 and n > 1:
         is_dup = torch.rand(n, generator=g, device=device) < dup_frac
@@ -213,6 +227,7 @@ def make_vectors_zipf_dev(n, dim, nnz, zipf_s, seed, device, dup_frac=0.05, bloc
         cand = (torch.rand(rows.numel(), generator=g, device=device, dtype=torch.float64) * rows.to(torch.float64)).to(torch.int64)
         last_base = torch.where(~is_dup, torch.arange(n, device=device), torch.zeros((), dtype=torch.int64, device=device))
         src = torch.cummax(last_base, 0).values[cand]  # nearest base (non-duplicate) row at or before the drawn one
+        src_all[rows] = src
         n_rep = max(1, nnz // 10)
         for b0 in range(0, rows.numel(), block):
             rr, ss = rows[b0:b0 + block], src[b0:b0 + block]
@@ -231,4 +246,4 @@ def make_vectors_zipf_dev(n, dim, nnz, zipf_s, seed, device, dup_frac=0.05, bloc
             val[rr] = torch.gather(v, 1, order)
     val /= val.norm(dim=1, keepdim=True)
     rowptr = torch.arange(0, (n + 1) * nnz, nnz, dtype=torch.int64, device=device)
-    return rowptr, idx, val
+    return (rowptr, idx, val, src_all) if return_src else (rowptr, idx, val)

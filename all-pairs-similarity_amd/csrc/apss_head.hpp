@@ -54,7 +54,6 @@ typedef __attribute__((ext_vector_type(16))) float apss_f32x16;
 
 constexpr int kHeadQBlock = 512;   // query slots per workgroup (8 waves x 64)
 constexpr int kHeadCTile = 64;     // candidate rows per LDS tile
-constexpr uint32_t kNoTerm = 0x7fffffffu;  // idx_tail value of an entry that lives in the dense block
 // candidate rows per LDS tile of k_head_gemm
 __host__ __device__ constexpr int head_tile_rows(int) { return kHeadCTile; }
 
@@ -76,8 +75,8 @@ __global__ void k_df_sample(const int64_t *rowptr, const int32_t *idx, int64_t n
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_head_pack: one wave per row of a CSR batch -> its row of W, its tail ratio |x_T| / |x| (the scale of the sparse
-// filter's shard rule), and (store rows) the entry-wise term array the index build reads, head entries masked out.
+// k_head_pack: one wave per row of a CSR batch -> its row of W and its tail ratio |x_T| / |x| (the scale of the sparse
+// filter's shard rule).
 // element offset of (row, chunk) in a tiled W of width kh
 // (kh: the TOTAL width of a W row -- 64 | 128 | 256, or 256 B for B blocks; chunk counts across the blocks)
 __host__ __device__ __forceinline__ int64_t head_chunk_off(int64_t row, int chunk, int kh) {
@@ -98,7 +97,6 @@ struct HeadPackArgs {
   uint16_t *W;             // tiled; CSR row r lands in W row w_row0 + r - row0
   int64_t w_row0, w_pad;   // w_pad: a multiple of 64 (the GEMM reads whole tiles)
   float *ratio_t;          // [..] |x_T| / |x| per row, indexed like the W rows
-  int32_t *idx_tail;       // same extent as idx (may be null): idx with head entries replaced by kNoTerm
   unsigned int *head_nonempty;  // += rows with at least one head entry
   // a term shard packs W from the batch as the caller handed it in (whole rows; its store keeps its term range only):
   const float *row_inv;    // [rows of the CSR] or null: factor of every value (APSS_FLAG_NORMALIZE, k_ingest_count)
@@ -126,7 +124,6 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
       const float v = a.val[k] * inv;
       const int32_t t = a.idx[k];
       const int32_t hp = a.head_pos[t];
-      if (a.idx_tail) a.idx_tail[k] = hp >= 0 ? (int32_t)kNoTerm : t;
       if (!(v > a.prune_above)) continue;
       full2 += v * v;
       if (hp < 0) t2 += v * v;
@@ -182,14 +179,74 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
   if (threadIdx.x == 0 && nz && a.head_nonempty) atomicAdd(a.head_nonempty, nz);
 }
 
-// the store's term array with the block's entries masked (what the index build reads), entries [k0, k1): a term shard's
-// store is its term range of every row, so the mask is made from the store, not by k_head_pack from the caller's batch
-__global__ void k_head_mask(const int32_t *idx, const int32_t *head_pos, int32_t *idx_tail, int64_t k0, int64_t k1) {
-  const int64_t k = k0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < k1) {
-    const int32_t t = idx[k];
-    idx_tail[k] = head_pos[t] >= 0 ? (int32_t)kNoTerm : t;
+// TAIL VIEW of a CSR batch: the same rows without the entries the dense block holds -- what the inverted index is built
+// from and what the sparse filter's rounds stage.  With a deep folded block four fifths of a row's entries are head terms;
+// left in the rows they would be staged every round only to find an empty posting segment.  Two passes around a scan, like
+// the ingest: count per row, then an ordered compaction by 16-lane groups.
+struct TailViewArgs {
+  const int64_t *rowptr;    // source CSR (absolute offsets), rows [row0, row1)
+  const int32_t *idx;
+  const float *val;
+  int64_t row0, row1;
+  const int32_t *head_pos;  // [dim] >= 0: the term lives in the dense block
+  int64_t *cnt;             // [row1 - row0] tail entries per row (pass 1 out, pass 2 in as its exclusive scan `off`)
+  const int64_t *off;       // [row1 - row0 + 1]
+  unsigned int *summary;    // [0] max tail entries of a row, [1] rows with at least one
+  int64_t dst_row0, dst_nnz0;  // destination: row r lands in view row dst_row0 + r - row0, its entries from dst_nnz0 + off[r - row0]
+  int64_t *o_rowptr;
+  int32_t *o_idx;
+  float *o_val;
+  uint32_t *o_erow;         // view row of every entry (may be null)
+};
+
+__global__ void k_tailv_count(TailViewArgs a) {
+  __shared__ unsigned sh[2];
+  if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t row = a.row0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  int c = 0;
+  if (row < a.row1)
+    for (int64_t k = a.rowptr[row] + gl, e = a.rowptr[row + 1]; k < e; k += kGroup) c += a.head_pos[a.idx[k]] < 0 ? 1 : 0;
+  for (int o = kGroup / 2; o; o >>= 1) c += __shfl_xor(c, o, kGroup);
+  if (gl == 0 && row < a.row1) {
+    a.cnt[row - a.row0] = c;
+    atomicMax(&sh[0], (unsigned)c);
+    if (c) atomicAdd(&sh[1], 1u);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (sh[0]) atomicMax(a.summary, sh[0]);
+    if (sh[1]) atomicAdd(a.summary + 1, sh[1]);
+  }
+}
+
+__global__ void k_tailv_write(TailViewArgs a) {
+  const int64_t row = a.row0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  if (row >= a.row1) return;
+  const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
+  const int64_t dr = a.dst_row0 + (row - a.row0);
+  int64_t out = a.dst_nnz0 + a.off[row - a.row0];
+  for (int64_t k0 = b; k0 < e; k0 += kGroup) {
+    const int64_t k = k0 + gl;
+    int32_t t = 0;
+    bool keep = false;
+    if (k < e) {
+      t = a.idx[k];
+      keep = a.head_pos[t] < 0;
+    }
+    const unsigned long long m = __ballot(keep);
+    const unsigned gm = (unsigned)((m >> (__lane_id() & ~(kGroup - 1))) & 0xffffu);
+    if (keep) {
+      const int64_t o = out + __popc(gm & ((1u << gl) - 1u));
+      a.o_idx[o] = t;
+      a.o_val[o] = a.val[k];
+      if (a.o_erow) a.o_erow[o] = (uint32_t)dr;
+    }
+    out += __popc(gm);
+  }
+  if (gl == 0) a.o_rowptr[dr + 1] = a.dst_nnz0 + a.off[row - a.row0 + 1];
 }
 
 // ---------------------------------------------------------------------------------------------------------

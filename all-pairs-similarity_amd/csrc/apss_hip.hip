@@ -180,14 +180,24 @@ struct apss_handle {
   int64_t head_eval_rows = 0;         // store size when the head policy last looked at the term distribution
   bool head_blocked = false;          // a call needed the plain path: no block until the next apss_clear
   std::vector<int32_t> head_terms;    // the block's terms, in block order
-  DevBuf<int32_t> head_pos, idx_tail; // [dim] term -> position | -1;  store idx with head entries masked (index build input)
+  DevBuf<int32_t> head_pos;           // [dim] term -> column of the block | -1
+  // tail view (apss_head.hpp): the rows without the block's entries -- index build input and the sparse filter's query rows
+  struct TailView {
+    DevBuf<int64_t> rowptr;
+    DevBuf<int32_t> idx;
+    DevBuf<float> val;
+    DevBuf<uint32_t> erow;
+    int64_t rows = 0, nnz = 0, max_nnz = 0, nonempty = 0, last_nonempty = 0;
+  };
+  TailView tv, qtv;                   // of the store rows [0, idx_rows); of the staged (outside) query batch
+  DevBuf<int64_t> tv_cnt, tv_off;
+  DevBuf<unsigned int> tv_sum;
   DevBuf<uint16_t> W, q_W;            // [rows x head_k] bf16 rows of the store / of a staged query batch
   DevBuf<uint32_t> df;
   DevBuf<unsigned long long> dedup_tab, head_ctr;
   DevBuf<int32_t> uq_q, uq_c;         // candidate list after k_pair_dedup
   DevBuf<float> uq_s;
   int64_t head_nonempty = 0, last_batch_head_nonempty = 0;
-  int64_t idx_tail_valid = 0;         // entries of idx_tail that are filled in
   double head_sample_frac = 0.0;      // fraction of sampled pairs the dense filter passed when the policy last looked
   hipEvent_t ev2 = nullptr, ev3 = nullptr;
   // stats
@@ -400,7 +410,6 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
     p.w_row0 = dst_row0;
     p.w_pad = w_pad;
     p.ratio_t = nullptr;  // k_ingest_count wrote this shard's ratio
-    p.idx_tail = nullptr;
     p.head_nonempty = reinterpret_cast<unsigned int *>(h->head_ctr.p);
     p.row_inv = (h->cfg.flags & APSS_FLAG_NORMALIZE) ? h->s_inv.p : nullptr;
     p.prune_above = (h->cfg.flags & APSS_FLAG_VALUE_PRUNE) ? (float)h->cfg.index_threshold : -INFINITY;
@@ -450,9 +459,10 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   if (!lds_build)
     HIPCHK(h, hipMemsetAsync(ix.seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
   BuildArgs b{};
-  b.rowptr = h->rowptr.p;
-  b.idx = h->head_k ? h->idx_tail.p : h->idx.p;  // dense-head entries are masked out of the inverted index
-  b.val = h->val.p;
+  // (a handle with a dense-head block builds from its tail view: the block's entries are not in the inverted index)
+  b.rowptr = h->head_k ? h->tv.rowptr.p : h->rowptr.p;
+  b.idx = h->head_k ? h->tv.idx.p : h->idx.p;
+  b.val = h->head_k ? h->tv.val.p : h->val.p;
   b.row0 = r0;
   b.row1 = h->idx_rows;
   b.cb = (int32_t)cb;
@@ -461,7 +471,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.seg_stride = stride;
   b.coarse = ix.coarse ? 1 : 0;
   b.seg_align = ix.align;
-  b.erow = h->erow.p;
+  b.erow = h->head_k ? h->tv.erow.p : h->erow.p;
   b.row_scale = scaled && ix.coarse ? h->sub.p : nullptr;  // shard rule: postings normalised by |x_g| / |x| (k_probe_coarse)
   b.coarse_shift = ix.coarse && ix.cb <= 32768 ? 1 : 0;  // must agree with k_probe_coarse's SLOT2 (the 512-thread kernels)
   b.coarse_wide = ix.coarse && ix.cb > 65536 ? 1 : 0;     // ... and with its WIDE (131072-row tiles)
@@ -556,14 +566,55 @@ inline bool head_allowed(const apss_handle *h) {
          !h->head_blocked && h->nonneg;
 }
 
-// term shard: the store's term array with the block's entries masked, entries of rows [row0, n_rows)
-int32_t head_mask_store(apss_handle *h, int64_t row0, int64_t nnz0) {
-  APSS_TRY(ensure(h, h->idx_tail, (size_t)std::max<int64_t>(h->nnz, 1), (size_t)(row0 ? h->idx_tail_valid : 0)));
-  if (h->nnz > nnz0)
-    hipLaunchKernelGGL(k_head_mask, dim3((unsigned)ceil_div(h->nnz - nnz0, 256)), dim3(256), 0, h->stream,
-                       (const int32_t *)h->idx.p, (const int32_t *)h->head_pos.p, h->idx_tail.p, nnz0, h->nnz);
+// tail view of rows [row0, row1) of a CSR batch (absolute offsets), appended to `v` as its rows [dst_row0, ..)
+int32_t build_tail_view(apss_handle *h, apss_handle::TailView &v, const int64_t *rowptr, const int32_t *idx, const float *val,
+                        int64_t row0, int64_t row1, int64_t dst_row0, bool with_erow) {
+  const int64_t n = row1 - row0;
+  if (dst_row0 == 0) v.rows = v.nnz = v.max_nnz = v.nonempty = 0;
+  v.last_nonempty = 0;
+  APSS_TRY(ensure(h, v.rowptr, (size_t)(dst_row0 + n + 1), (size_t)(dst_row0 ? dst_row0 + 1 : 0)));
+  if (dst_row0 == 0) HIPCHK(h, hipMemsetAsync(v.rowptr.p, 0, sizeof(int64_t), h->stream));
+  if (n <= 0) return APSS_OK;
+  APSS_TRY(ensure(h, h->tv_cnt, (size_t)n + 1));
+  APSS_TRY(ensure(h, h->tv_off, (size_t)n + 1));
+  APSS_TRY(ensure(h, h->tv_sum, 2));
+  HIPCHK(h, hipMemsetAsync(h->tv_sum.p, 0, 2 * sizeof(unsigned int), h->stream));
+  TailViewArgs a{};
+  a.rowptr = rowptr;
+  a.idx = idx;
+  a.val = val;
+  a.row0 = row0;
+  a.row1 = row1;
+  a.head_pos = h->head_pos.p;
+  a.cnt = h->tv_cnt.p;
+  a.summary = h->tv_sum.p;
+  const unsigned blocks = (unsigned)ceil_div(n * kGroup, 256);
+  hipLaunchKernelGGL(k_tailv_count, dim3(blocks), dim3(256), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
-  h->idx_tail_valid = h->nnz;
+  APSS_TRY(scan_i64(h, (const int64_t *)h->tv_cnt.p, h->tv_off.p, n));
+  int64_t total = 0;
+  unsigned int sum[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(&total, h->tv_off.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(sum, h->tv_sum.p, sizeof(sum), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const int64_t nnz0 = v.nnz;
+  APSS_TRY(ensure(h, v.idx, (size_t)std::max<int64_t>(nnz0 + total, 1), (size_t)nnz0));
+  APSS_TRY(ensure(h, v.val, (size_t)std::max<int64_t>(nnz0 + total, 1), (size_t)nnz0));
+  if (with_erow) APSS_TRY(ensure(h, v.erow, (size_t)std::max<int64_t>(nnz0 + total, 1), (size_t)nnz0));
+  a.off = h->tv_off.p;
+  a.dst_row0 = dst_row0;
+  a.dst_nnz0 = nnz0;
+  a.o_rowptr = v.rowptr.p;
+  a.o_idx = v.idx.p;
+  a.o_val = v.val.p;
+  a.o_erow = with_erow ? v.erow.p : nullptr;
+  hipLaunchKernelGGL(k_tailv_write, dim3(blocks), dim3(256), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  v.rows = dst_row0 + n;
+  v.nnz = nnz0 + total;
+  v.max_nnz = std::max<int64_t>(v.max_nnz, sum[0]);
+  v.nonempty += sum[1];
+  v.last_nonempty = sum[1];
   return APSS_OK;
 }
 
@@ -573,8 +624,6 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
   const int64_t rows_pad = ceil_div(h->idx_rows, kHeadQBlock) * kHeadQBlock + kHeadCTile;
   APSS_TRY(ensure(h, h->W, (size_t)(rows_pad * kh), (size_t)(ceil_div(row0, kHeadCTile) * kHeadCTile * kh)));  // (tiled: whole tiles)
   APSS_TRY(ensure(h, h->sub, (size_t)h->idx_rows, (size_t)row0));
-  APSS_TRY(ensure(h, h->idx_tail, (size_t)std::max<int64_t>(h->nnz, 1), (size_t)(row0 ? h->idx_tail_valid : 0)));
-  h->idx_tail_valid = h->nnz;
   APSS_TRY(ensure(h, h->head_ctr, 4));
   HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
   {
@@ -590,7 +639,6 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
     a.w_row0 = row0;
     a.w_pad = rows_pad;  // the rows past the last one are zero rows: a GEMM tile or query block may read them
     a.ratio_t = h->sub.p;
-    a.idx_tail = h->idx_tail.p;
     a.head_nonempty = reinterpret_cast<unsigned int *>(h->head_ctr.p);
     a.row_inv = nullptr;
     a.prune_above = -INFINITY;  // (the store holds the rows as they are scored)
@@ -635,7 +683,6 @@ int32_t head_sample_selectivity(apss_handle *h, double *frac) {
   p.w_row0 = 0;
   p.w_pad = ceil_div(S, kHeadQBlock) * kHeadQBlock;
   p.ratio_t = h->sub.p;
-  p.idx_tail = nullptr;
   p.head_nonempty = nullptr;
   p.row_inv = nullptr;
   p.prune_above = -INFINITY;
@@ -762,8 +809,9 @@ int32_t build_index(apss_handle *h, int64_t row0) {
     }
     if (h->head_k) {
       h->cx.cb = std::min(h->cx.cb, 65536);  // the sparse half runs a 512-thread shard-rule kernel
-      if (h->sharded) APSS_TRY(head_mask_store(h, row0, row0 ? h->idx_tail_valid : 0));  // (W and the ratios: ingest)
-      else APSS_TRY(head_pack_store(h, row0));
+      if (!h->sharded) APSS_TRY(head_pack_store(h, row0));  // (a term shard's W and ratios: ingest, from the caller's whole rows)
+      const int64_t tv0 = row0 == h->tv.rows ? row0 : 0;  // (append, or start over when the view is not exactly the rows before)
+      APSS_TRY(build_tail_view(h, h->tv, h->rowptr.p, h->idx.p, h->val.p, tv0, h->idx_rows, tv0, true));
     }
   } else if (h->head_k && h->sharded) {
     // a shard cannot leave the partition its peers were given: the block's terms are in no shard's index
@@ -1015,16 +1063,25 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
   g.res_cap = a.res_cap;
   g.counters = a.counters;
   g.head_pairs = h->head_ctr.p + 1;
-  const dim3 grid((unsigned)((int64_t)g.n_qblocks * g.n_panels));
   g.kt = kt;
-  g.blk = 0;
-  if (kh == 64) hipLaunchKernelGGL(k_head_gemm<64>, grid, dim3(512), 0, h->stream, g);
-  else if (kh == 128) hipLaunchKernelGGL(k_head_gemm<128>, grid, dim3(512), 0, h->stream, g);
-  else hipLaunchKernelGGL(k_head_gemm<256>, grid, dim3(512), 0, h->stream, g);
-  for (int b = 1; b < n_blocks; ++b) {  // the further blocks of a wide head: the same contraction over the next 256 terms, no pair statistic
+  // one launch multiplies a group of query blocks sized for about a second of matrix-core time (4e12 elements): a join of ten
+  // million rows becomes a sequence of launches of bounded duration instead of one kernel that runs for a quarter of a minute
+  const int64_t all_qblocks = g.n_qblocks, first_qblock0 = g.qblock0;
+  const int64_t per_launch = std::max<int64_t>(1, (int64_t)(4e12 / ((double)kHeadQBlock * (double)ct * (double)my_ctiles)));
+  for (int b = 0; b < n_blocks; ++b) {  // (block 1: the folded terms -- the same contraction, no pair statistic)
     g.blk = b;
-    hipLaunchKernelGGL((k_head_gemm<256, false>), grid, dim3(512), 0, h->stream, g);
+    for (int64_t q0 = 0; q0 < all_qblocks; q0 += per_launch) {
+      g.n_qblocks = (int32_t)std::min<int64_t>(per_launch, all_qblocks - q0);
+      g.qblock0 = first_qblock0 + q0 * kHeadQBlock;
+      const dim3 grid((unsigned)((int64_t)g.n_qblocks * g.n_panels));
+      if (b > 0) hipLaunchKernelGGL((k_head_gemm<256, false>), grid, dim3(512), 0, h->stream, g);
+      else if (kh == 64) hipLaunchKernelGGL(k_head_gemm<64>, grid, dim3(512), 0, h->stream, g);
+      else if (kh == 128) hipLaunchKernelGGL(k_head_gemm<128>, grid, dim3(512), 0, h->stream, g);
+      else hipLaunchKernelGGL(k_head_gemm<256>, grid, dim3(512), 0, h->stream, g);
+    }
   }
+  g.n_qblocks = (int32_t)all_qblocks;
+  g.qblock0 = first_qblock0;
   HIPCHK(h, hipGetLastError());
   // multiplied elements: every (query block, candidate tile) the grid does not skip, at MFMA granularity
   double tiles = 0;
@@ -1067,6 +1124,32 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   if (nq == 0 || h->n_rows == 0 || q_nnz_end <= 0 || h->nnz == 0) return APSS_OK;  // nothing can share a term
   if (nq > 0x7fffffffLL) return fail(h, APSS_E_INVALID, "query batch too large");
 
+  // What the SPARSE filter stages: the query rows themselves -- or, on a handle with a dense-head block, their tail view
+  // (the rows without the block's entries; a stored batch's was made when it was indexed, an outside batch's is made here).
+  // Exact rescoring, the waiting rows' direct scoring and apss_partial_scores_dev keep reading the whole rows.
+  const int64_t *s_rowptr = q_rowptr;
+  const int32_t *s_idx = q_idx;
+  const float *s_val = q_val;
+  int64_t s_max_nnz = q_max_nnz, s_nnz_end = q_nnz_end;
+  if (h->head_k > 0) {
+    if (q_slot_first >= 0 && q_slot_first < h->idx_rows) {
+      s_rowptr = h->tv.rowptr.p + q_slot_first;
+      s_idx = h->tv.idx.p;
+      s_val = h->tv.val.p;
+      s_max_nnz = h->tv.max_nnz;
+      s_nnz_end = h->tv.nnz;
+    } else {
+      APSS_TRY(build_tail_view(h, h->qtv, q_rowptr, q_idx, q_val, 0, nq, 0, false));
+      s_rowptr = h->qtv.rowptr.p;
+      s_idx = h->qtv.idx.p;
+      s_val = h->qtv.val.p;
+      s_max_nnz = h->qtv.max_nnz;
+      s_nnz_end = h->qtv.nnz;
+    }
+  }
+  const int64_t c_max_nnz = h->head_k > 0 ? h->tv.max_nnz : h->store_max_nnz;  // longest indexed row
+  const int64_t idx_nnz = h->head_k > 0 ? std::max<int64_t>(h->tv.nnz, 1) : h->nnz;  // postings in the inverted index
+
   const double theta = h->cfg.theta;
   int mode;
   if (!(theta > 0.0)) mode = 2;
@@ -1083,7 +1166,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // accumulator units per 1.0: a 16-bit sum holds S * |q||c| (fp16 weights: + 2^-11) plus one unit per shared term
   // S = the largest power of two that fits (2^15 for unit-norm input); un-normalised input gets a smaller one as long as
   // the threshold in units stays well above the round-up bias (one unit per shared term), else the filter passes too much
-  const double cx_shared = (double)std::min<int64_t>(q_max_nnz, h->store_max_nnz);
+  const double cx_shared = (double)std::min<int64_t>(s_max_nnz, c_max_nnz);
   const double cx_room = 65535.0 - cx_shared;
   double cx_scale = 0.0;
   for (int k = 15; k >= 4 && cx_scale == 0.0; --k)
@@ -1100,11 +1183,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // dense-head block (and long queries over 65536-row tiles) has no such instantiation and keeps the general kernel
   const bool shard_rule = h->sharded || hybrid_wanted;
   const bool cx_signed = mode == 1 && !(h->cfg.flags & APSS_FLAG_FORCE_SCAN) && !hybrid_wanted &&
-                         (h->cx.cb <= 32768 || q_max_nnz <= 512) && !dbg.chunk8 && !dbg.window;
+                         (h->cx.cb <= 32768 || s_max_nnz <= 512) && !dbg.chunk8 && !dbg.window;
   // 65536-row tiles (term shards; the sparse regime of a plain handle): the 8-bit filter -- 65536 candidates in 64 KB, two
   // 512-thread workgroups per CU -- if this call's norms and row lengths leave room for its sums
   const bool big_shard_tiles = shard_rule && h->cx.cb > 32768;
-  const double a8_scale = h->cx.cb >= 65536 && mode == 0 && q_max_nnz <= 512 && !dbg.no_acc8 && !h->no_acc8 && !dbg.chunk8
+  const double a8_scale = h->cx.cb >= 65536 && mode == 0 && s_max_nnz <= 512 && !dbg.no_acc8 && !h->no_acc8 && !dbg.chunk8
                               ? acc8_scale(bound, cx_shared, theta) : 0.0;
   if ((big_shard_tiles || h->cx.cb > 65536) && !(a8_scale > 0)) {
     // not this time (a long row, a large norm, signed weights): back to 16-bit accumulators over smaller tiles, for good
@@ -1122,7 +1205,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const bool coarse_path = h->use_coarse && (mode == 0 || cx_signed) && (cx_selective || a8_scale > 0) && cx_fp16_ok && !forced_general && nq < (1LL << 30) &&
                            !(shard_rule && h->cx.cb > 32768 && !(a8_scale > 0)) &&
                            !dbg.exact_accum && cx_scale > 0 && cx_theta < 65000.0 && (shard_rule || cx_theta - 2 >= 1.0) &&
-                           std::min(h->store_max_nnz * (int64_t)h->cx.cb, h->nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
+                           std::min(c_max_nnz * (int64_t)h->cx.cb, idx_nnz) + (int64_t)kSegAlignC * h->cfg.dim < (1LL << 27);
   // rows waiting in the tail are scored pair by pair after the join over the index; that needs the two-pass path's final
   // list and a bounded number of pairs -- otherwise they are folded into the index first
   const int64_t tail_n = h->n_rows - h->idx_rows;
@@ -1154,13 +1237,13 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.ext_id = h->ext.p;
   a.c_scale = shard_rule ? h->sub.p : nullptr;
   a.n_rows = h->idx_rows;
-  a.q_rowptr = q_rowptr;
-  a.q_idx = q_idx;
-  a.q_val = q_val;
+  a.q_rowptr = s_rowptr;
+  a.q_idx = s_idx;
+  a.q_val = s_val;
   a.q_ext = q_ext;
   a.q_scale = shard_rule ? q_sub : nullptr;
   a.nq = (int32_t)nq;
-  a.q_nnz_end = q_nnz_end;
+  a.q_nnz_end = s_nnz_end;
   // ~2 workgroups per CU per tile in flight at once, tiles swept one after another (tile-major grid) so the
   // chip works on one tile's postings at a time and they stay in L2 / Infinity Cache
   const int64_t want_chunks = dbg.chunks > 0 ? dbg.chunks : 1024;
@@ -1208,11 +1291,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     cxv.block = h->cx.cb > 65536 || (h->cx.cb > 32768 && !cxv.acc8) ? 1024 : 512;
     cxv.shard = shard_rule;
     cxv.chunk = dbg.chunk8 ? 8 : 16;
-    cxv.vrows = q_max_nnz > 512;
+    cxv.vrows = s_max_nnz > 512;
     cxv.sgn = cx_signed;
     const double nw = cxv.block / kWave;
-    const double seg = (double)h->cx.cb * ((double)h->nnz / (double)h->n_rows) / (double)h->cfg.dim;  // postings per (tile, term)
-    double q_terms = (double)q_nnz_end / (double)nq;
+    const double seg = (double)h->cx.cb * ((double)idx_nnz / (double)h->n_rows) / (double)h->cfg.dim;  // postings per (tile, term)
+    double q_terms = (double)s_nnz_end / (double)nq;
     // a shard holds a binomial share of each query's terms; a window that overflows costs a whole-tile clear, so the
     // shard-rule launches size it for the upper end (3 sigma) and for segments one chunk longer than their mean
     const double t_hi = shard_rule ? q_terms + 3.0 * std::sqrt(q_terms) : q_terms;
@@ -1243,9 +1326,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     // then holds a 1/A share of the ROUND's chunks, not the chunks of the wave's own terms.
     // Staging lanes per term: as many as keep the staging waves at <= a quarter of the workgroup.
     int flat_group_log2 = 2;
-    while (flat_group_log2 > 0 && ceil_div(q_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
+    while (flat_group_log2 > 0 && ceil_div(s_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
     if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
-    const int64_t flat_waves = std::max<int64_t>(1, ceil_div(q_max_nnz, kWave >> flat_group_log2));
+    const int64_t flat_waves = std::max<int64_t>(1, ceil_div(s_max_nnz, kWave >> flat_group_log2));
     // Where it is taken (measured on C3 and its shards, ms of the filter kernel, k_probe_even vs k_probe_coarse): term shards
     // T = 8: 23.4 vs 40.5, T = 4: 35.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 58.7 vs 77.9; the sparse
     // regime's 1024-thread kernel (C5's shape at a fifth of N): 218.2 vs 291.5; the plain handle of C3 itself (100-term rows,
@@ -1263,7 +1346,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       // with a whole-tile clear, ~2 % of them; at 3 sigma the T = 8 shard took a 3-step window: 24.8 vs 23.2 ms)
       double round_chunks = q_terms * cpt + 2.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
       // (a plain handle's rows are whole rows: no binomial share of the terms; the longest row bounds the round)
-      if (!shard_rule) round_chunks = std::min(round_chunks, 1.05 * (double)q_max_nnz * cpt);
+      if (!shard_rule) round_chunks = std::min(round_chunks, 1.05 * (double)s_max_nnz * cpt);
       int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
       // (a window that overflows most rounds pays a whole-tile clear each time)
       const bool fits = ue <= 7 && !cxv.sgn && (wide_ok || add_waves * std::max(2, ue) <= nw * (double)cxv.u);
@@ -1271,7 +1354,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       ev.u = ue;
       if (dbg.diag)
         fprintf(stderr, "[apss diag] even? block %d u %d | F %lld G %d A %.0f chunks %.1f ue %d fits %d exists %d q_max %lld q_terms %.1f seg %.1f\n", cxv.block, cxv.u,
-                (long long)flat_waves, 1 << flat_group_log2, add_waves, round_chunks, ue, (int)fits, (int)cx_variant_exists(ev), (long long)q_max_nnz, q_terms, seg);
+                (long long)flat_waves, 1 << flat_group_log2, add_waves, round_chunks, ue, (int)fits, (int)cx_variant_exists(ev), (long long)s_max_nnz, q_terms, seg);
       if (fits && cx_variant_exists(ev)) {
         cxv = ev;
         a.flat_waves = (int32_t)flat_waves;
@@ -1306,12 +1389,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     return APSS_OK;
   };
 
-  if (coarse_path && q_max_nnz > vrow_part) {
+  if (coarse_path && s_max_nnz > vrow_part) {
     // queries of more terms than a round takes: cut them into parts that share the accumulators
     APSS_TRY(ensure(h, h->vrow_np, (size_t)nq + 1));
     APSS_TRY(ensure(h, h->vrow_first, (size_t)nq + 2));
     APSS_TRY(ensure(h, h->vq_first, (size_t)nq + 1));
-    hipLaunchKernelGGL(k_vrow_count, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, h->stream, q_rowptr, nq, vrow_part, h->vrow_np.p);
+    hipLaunchKernelGGL(k_vrow_count, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, h->stream, s_rowptr, nq, vrow_part, h->vrow_np.p);
     APSS_TRY(scan_i64(h, (const int64_t *)h->vrow_np.p, h->vrow_first.p, nq));
     HIPCHK(h, hipGetLastError());
     int64_t nv = 0;
@@ -1319,7 +1402,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     HIPCHK(h, hipStreamSynchronize(h->stream));
     APSS_TRY(ensure(h, h->vrow_ptr, (size_t)nv + 1));
     APSS_TRY(ensure(h, h->vrow_q, (size_t)nv + 1));
-    hipLaunchKernelGGL(k_vrow_fill, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, h->stream, q_rowptr, nq, vrow_part,
+    hipLaunchKernelGGL(k_vrow_fill, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, h->stream, s_rowptr, nq, vrow_part,
                        (const int64_t *)h->vrow_first.p, h->vq_first.p, h->vrow_ptr.p, h->vrow_q.p);
     HIPCHK(h, hipGetLastError());
     a.vq_first = h->vq_first.p;
@@ -1331,7 +1414,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   const int64_t total_tiles = ix.n_tiles;
   int64_t tiles_per_launch = std::max<int64_t>(1, total_tiles);
   if (total_tiles > 0) {
-    const double per_tile = (double)q_nnz_end * ((double)h->nnz / (double)total_tiles / (double)h->cfg.dim) + 1.0;
+    const double per_tile = (double)s_nnz_end * ((double)idx_nnz / (double)total_tiles / (double)h->cfg.dim) + 1.0;
     tiles_per_launch = (int64_t)std::min<double>((double)total_tiles, std::max(1.0, std::floor(2e11 / per_tile)));
     if (dbg.tiles_per_launch > 0) tiles_per_launch = dbg.tiles_per_launch;
     tiles_per_launch = std::min<int64_t>(tiles_per_launch, std::max<int64_t>(1, 2000000000LL / std::max(1, a.n_chunks)));
@@ -1424,7 +1507,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     h->st.candidate_pairs = (int64_t)c[kCtrCands];
     // the speed paths count a stored query's touch of its own slot; it is not a (q, c != q) pair
     if ((wave_path || coarse_path) && q_slot_base >= 0)
-      h->st.candidate_pairs -= (q_slot_base == 0 && nq == h->n_rows) ? h->store_nonempty : h->last_batch_nonempty;
+      h->st.candidate_pairs -= h->head_k > 0 ? ((q_slot_base == 0 && nq == h->n_rows) ? h->tv.nonempty : h->tv.last_nonempty)
+                                             : ((q_slot_base == 0 && nq == h->n_rows) ? h->store_nonempty : h->last_batch_nonempty);
     if (hybrid) {
       HIPCHK(h, hipEventElapsedTime(&ms, h->ev2, h->ev3));
       h->st.head_ms += ms;
@@ -1662,7 +1746,6 @@ int32_t pack_query_head(apss_handle *h, const int64_t *rowptr, const int32_t *id
   a.w_row0 = 0;
   a.w_pad = q_pad;
   a.ratio_t = h->q_sub.p;
-  a.idx_tail = nullptr;
   a.head_nonempty = nullptr;
   a.row_inv = nullptr;
   a.prune_above = -INFINITY;
@@ -1784,7 +1867,9 @@ void apss_destroy(apss_handle *h) {
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst); release(h->scan_tmp);
   release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val); release(h->in_val64); release(h->vq_first); release(h->vrow_q); release(h->vrow_ptr); release(h->vrow_np); release(h->vrow_first);
   release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword); release(h->dbg);
-  release(h->head_pos); release(h->idx_tail); release(h->W); release(h->q_W); release(h->df); release(h->dedup_tab);
+  release(h->head_pos); release(h->W);
+  for (apss_handle::TailView *v : {&h->tv, &h->qtv}) { release(v->rowptr); release(v->idx); release(v->val); release(v->erow); }
+  release(h->tv_cnt); release(h->tv_off); release(h->tv_sum); release(h->q_W); release(h->df); release(h->dedup_tab);
   release(h->head_ctr); release(h->uq_q); release(h->uq_c); release(h->uq_s);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1944,7 +2029,6 @@ int32_t apss_clear(apss_handle *h) {
   h->q_nonneg = true;
   h->no_acc8 = h->dbgcfg.no_acc8;
   h->downgrades = 0;
-  h->idx_tail_valid = 0;
   h->store_max_nnz = 0;
   h->store_max_norm2 = 0.f;
   h->store_nonempty = 0;

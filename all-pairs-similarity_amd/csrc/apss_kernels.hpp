@@ -330,7 +330,7 @@ __device__ __forceinline__ uint32_t pack_coarse_wide(uint32_t slot, float w) {
 
 struct BuildArgs {
   const int64_t *rowptr;
-  const int32_t *idx;             // term of every entry; an entry held by the dense-head block has kNoTerm here
+  const int32_t *idx;             // term of every entry (a handle with a dense-head block builds from its tail view: apss_head.hpp)
   const float *val;
   int64_t row0, row1;
   int32_t cb;
@@ -358,7 +358,7 @@ __global__ void k_tile_hist(BuildArgs a) {
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
   for (int64_t k = b + lane; k < e; k += kWave) {
     const int32_t t = a.idx[k];
-    if ((uint32_t)t < (uint32_t)a.dim) atomicAdd(&sg[t].y, 1u);  // (an entry of the dense-head block carries no term here)
+    if ((uint32_t)t < (uint32_t)a.dim) atomicAdd(&sg[t].y, 1u);
   }
 }
 
@@ -408,7 +408,7 @@ __global__ void k_tile_scatter(BuildArgs a) {
   const int64_t b = a.rowptr[row], e = a.rowptr[row + 1];
   for (int64_t k = b + lane; k < e; k += kWave) {
     const int32_t t = a.idx[k];
-    if ((uint32_t)t >= (uint32_t)a.dim) continue;  // dense-head entry: not in the inverted index
+    if ((uint32_t)t >= (uint32_t)a.dim) continue;
     // one 64-bit returning atomic on {start, cursor}: bumps the cursor (high word) and brings the start along
     const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(&sg[t]), 1ull << 32);
     const uint32_t pos = (uint32_t)old + (uint32_t)(old >> 32);

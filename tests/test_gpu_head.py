@@ -215,3 +215,19 @@ def test_maildir_tfidf_with_a_forced_head_block(engine):
         got, st = _join(engine, dim, theta, z["rowptr"], z["indices"], z["values"], head_terms=kh)
         assert st["head_terms"] == kh and st["head_pairs"] > 0
         assert_same_pairs(got, want, theta)
+
+
+def test_power_law_property_without_the_oracle_reduced():
+    """the oracle-free check of profiles/fullsize_powerlaw.py (BASELINE.json configs[4] at N = 10M: every reported pair's
+    score against a direct float64 dot, every planted near-duplicate pair reported) at N = 150k, where it takes seconds:
+    configs[4]'s dim, nnz, distribution and threshold, the library's own head policy"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fullsize_powerlaw", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "fullsize_powerlaw.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(150_000, 1_000_000, 200, 0.9)
+    assert out["missing"] == 0 and out["planted_pairs_required"] > 5000 and out["max_abs_score_error"] <= 1e-5
+    assert out["head_terms"] >= 256 and out["head_pairs"] > 0.9 * out["pairs_n_squared"]
+    assert out["posting_visits"] < 0.01 * out["posting_visits_all_sparse"]  # the head took the long posting lists
