@@ -65,6 +65,19 @@ def hip_head_chooser(dim, theta, device, head_terms=0, sample_rows=131072):
     return choose
 
 
+def limit_head_depth(head, df, n_rows, T, min_tail_terms=8.0):
+    """A deep head leaves few tail terms per row, and T term ranges cut them T ways: a row with a single term in a range
+    pairs up at within-range cosine 1 with every row sharing it, and the candidate rule stops being selective (C3 with
+    Zipf(1) terms, 8192-term head, T = 8: 2.6 tail terms per row and shard, 3.3e7 candidates per shard instead of 2e5 at
+    T = 2).  Keep the head only as deep as leaves about `min_tail_terms` tail terms per row and shard; never shallower
+    than the 256 terms that hold the long posting lists."""
+    k = int(head.size)
+    total = int(df.sum())
+    while k > 256 and (total - int(df[head[:k]].sum())) / max(1, n_rows) / T < min_tail_terms:
+        k //= 2
+    return head[:max(k, 256)] if head.size > 256 else head
+
+
 class HipShardEngine:
     """One shard resident on one MI355X (libapss_hip.so through the C ABI; no fallback): the postings of the terms in
     `term_range` for the candidate rows in `row_range`.  Queries are always all rows of the batch.
@@ -205,10 +218,14 @@ class ShardedJoin:
     def load(self, rp, idx, val):
         """every rank holds the same batch (same seed / same broadcast); each indexes only its terms x rows"""
         df = np.bincount(idx, minlength=self.dim)
+        self.tail_terms_per_row_and_shard = float(idx.size) / max(1, len(rp) - 1) / self.T
         if self.T > 1 and self.head_mode >= 0:
             self.head = self._decide_head(rp, idx, val)
+            if self.head_mode == 0:
+                self.head = limit_head_depth(self.head, df, len(rp) - 1, self.T)
             df = df.copy()
             df[self.head] = 0  # the block's terms are in no shard's index: the ranges balance the tail's visits
+            self.tail_terms_per_row_and_shard = float(df.sum()) / max(1, len(rp) - 1) / self.T
         self.ranges = term_ranges(df, self.T)
         self.term_range = self.ranges[self.ti]
         self.n = len(rp) - 1
@@ -285,7 +302,8 @@ class ShardedJoin:
             "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
             "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes,
                          "union": int(uniq.numel()), "all_gather_bytes_per_rank": 8 * max(sizes + [1]) * self.T,
-                         "all_reduce_bytes": 4 * int(uniq.numel()), "term_ranges": self.ranges},
+                         "all_reduce_bytes": 4 * int(uniq.numel()), "term_ranges": self.ranges,
+                         "tail_terms_per_row_and_shard": self.tail_terms_per_row_and_shard},
         }
         if return_pairs:  # this rank's group result (the whole result when D == 1)
             return uq[keep].cpu().numpy(), uc[keep].cpu().numpy(), part[keep].cpu().numpy()
