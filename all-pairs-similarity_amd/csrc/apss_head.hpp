@@ -284,10 +284,12 @@ struct HeadGemmArgs {
   uint64_t res_cap;
   unsigned long long *counters;    // [kCtrResults] shared with the sparse filter
   unsigned long long *head_pairs;  // += elements with a positive dot (pairs sharing a head term), self pairs included
+  unsigned long long *clk;         // diagnostic kernel of the microbenchmark only: per workgroup {shader cycles, 100-MHz ticks}
 };
 
-template <int KH, bool COUNT = true>
-__global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
+template <int KH, bool COUNT = true, bool PIPE3 = true, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) {
+  constexpr int QB = 64 * NW;                 // query slots per workgroup (kHeadQBlock in the library; 256 in an experiment of the microbenchmark)
   constexpr int KS = KH / 16;                 // k-steps of the 32x32x16 MFMA
   constexpr int SPK = 16 / KS;                // epilogue scan steps (2 accumulators each) per k-step of the other half
   static_assert(SPK * KS == 16, "KH is 64, 128 or 256");
@@ -299,11 +301,11 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
   constexpr int SUBB = kHeadCTile * ROWB;     // bytes per sub-tile
   constexpr int TILEB = CT * ROWB;            // bytes per tile (contiguous in HBM: consecutive 64-row tiles of W)
   constexpr int PIECES = TILEB / 1024;        // 1-KiB DMA pieces per tile
-  constexpr int PPW = PIECES / 8;             // pieces per wave
+  constexpr int PPW = PIECES / NW;            // pieces per wave
   constexpr int PF = 2;                       // B fragments requested ahead of the MFMAs that use them
-  static_assert(PIECES % 8 == 0, "every wave copies the same number of pieces");
-  __shared__ __attribute__((aligned(1024))) unsigned char ldsb[2 * TILEB];
-  __shared__ float scratch[8 * 16 * kWave];  // reporting path only: one 32 x 32 accumulator block per wave
+  static_assert(PIECES % NW == 0, "every wave copies the same number of pieces");
+  __shared__ __attribute__((aligned(1024))) unsigned char ldsb[(PIPE3 ? 3 : 2) * TILEB];
+  __shared__ float scratch[NW * 16 * kWave];  // reporting path only: one 32 x 32 accumulator block per wave
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
@@ -311,15 +313,16 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
   const int panel = blockIdx.x % a.n_panels;
   const int qb = a.n_qblocks - 1 - (int)(blockIdx.x / a.n_panels);
   const bool stored = a.q_slot_base >= 0;
-  const int64_t B0 = a.qblock0 + (int64_t)qb * kHeadQBlock;  // first query slot of this block
+  const int64_t B0 = a.qblock0 + (int64_t)qb * QB;  // first query slot of this block
   const int64_t qs0 = stored ? a.q_slot_base : 0;            // slot of query row 0
 
   // panel p = candidate tiles p, p + P, p + 2P, ...: interleaved, so that the triangle of a stored batch (tiles above
   // the query block are skipped: the block that owns them reports the mirrored pairs) is cut evenly over the panels,
   // hence over the XCDs
-  const int t_lo = a.part + a.n_parts * panel, t_step = a.n_parts * a.n_panels;
+  const int n_parts = max(a.n_parts, 1);  // (a zero-initialised argument block must not make the tile loop stand still)
+  const int t_lo = a.part + n_parts * panel, t_step = n_parts * a.n_panels;
   int t_hi = a.n_ctiles;
-  if (stored) t_hi = min(t_hi, (int)((B0 + kHeadQBlock) / CT));
+  if (stored) t_hi = min(t_hi, (int)((B0 + QB) / CT));
   if (t_lo >= t_hi) return;
 
   // ---- A fragments: lane (r, hh) of block m holds W[slot][16 kk + 8 hh .. + 8) = chunk 2 kk + hh of its row; the 32
@@ -373,6 +376,9 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
     uint32_t pos;
   };
   auto scan = [&](Half &hf, const apss_f32x16 (&ac)[2], const int step) {  // step 0..15: elements 2 step, 2 step + 1 of 32
+#ifdef APSS_GEMM_NOEPI  // (microbenchmark experiment only: the tile stream without its epilogue; results are garbage)
+    if (step != 0) return;
+#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = 2 * step + j;
@@ -453,10 +459,81 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
   apss_f32x16 acc0[2], acc1[2];
   Half h0{0.f, 0u}, h1{0.f, 0u};
   int64_t pend = -1;  // first candidate row of the column block whose scan is pending in acc1 / h1 (-1: none)
+  if constexpr (PIPE3) {
+    // THREE tile buffers and the workgroup barrier in the MIDDLE of a tile.  With the barrier at the tile boundary every
+    // wave of the workgroup -- both waves of every SIMD -- stopped at the same point with no MFMA left to issue and, once
+    // released, first had to wait for its B fragments from LDS: the matrix pipe idled through arrival skew + an LDS round
+    // trip per tile (SQ counters: MFMA busy 0.67 of the kernel's cycles at a measured in-kernel clock of 2.39 GHz, i.e. no
+    // DVFS give-back to blame).  Here a wave runs from the second half of tile t straight into the first half of tile
+    // t + 1: tile t + 1 has been complete in LDS since the barrier in the middle of tile t, so its first fragments are
+    // requested during tile t's last MFMAs (a rolling prefetch queue across halves and tiles), and the barrier a wave meets
+    // in mid-tile finds the fragments of the MFMAs behind it already in registers.  That barrier says "tile t + 1 has
+    // landed for everyone, and everyone is past tile t - 1"; the copy of tile t + 2 into tile t - 1's buffer follows it.
+    apss_bf16x8 bq[PF];
+    auto mma_run = [&](apss_f32x16 (&ac)[2], const unsigned char *tb, const int n, const unsigned char *tb_next, const int n_next,
+                       auto &&between) {
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const apss_bf16x8 b = bq[kk % PF];
+        bq[kk % PF] = kk + PF < KS ? ldfrag(tb, n, kk + PF) : ldfrag(tb_next, n_next, kk + PF - KS);
+        if (kk == 0) {
+          const apss_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][kk], b, zero, 0, 0, 0);
+          ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][kk], b, zero, 0, 0, 0);
+        } else {
+          ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][kk], b, ac[0], 0, 0, 0);
+          ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][kk], b, ac[1], 0, 0, 0);
+        }
+        between(kk);
+      }
+    };
+    static_assert(KS % PF == 0 && KS >= PF, "the prefetch queue's slots line up across halves");
+    copy_tile(t_lo, 0);
+    if (t_lo + t_step < t_hi) {
+      copy_tile(t_lo + t_step, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");  // the first tile's pieces (loads complete in issue order)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const unsigned char *tb = ldsb, *tbn = ldsb + TILEB, *tbnn = ldsb + 2 * TILEB;
+    if (wave_live) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) bq[j] = ldfrag(tb, 0, j);
+    }
+    for (int t = t_lo; t < t_hi; t += t_step) {
+      const int64_t t_row0 = (int64_t)t * CT;
+      if (wave_live) {
+        if (pend >= 0) {
+          mma_run(acc0, tb, 0, tb, 1, [&](const int kk) {
+#pragma unroll
+            for (int j = 0; j < SPK; ++j) scan(h1, acc1, kk * SPK + j);
+          });
+          finish(h1, acc1, pend);
+        } else {
+          mma_run(acc0, tb, 0, tb, 1, [&](const int) {});
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t + 1 have landed
+      __syncthreads();                                   // ... and everyone's; nobody reads tile t - 1 any more
+      if (t + 2 * t_step < t_hi) copy_tile(t + 2 * t_step, (int)((tbnn - ldsb) / TILEB));
+      if (wave_live) {
+        mma_run(acc1, tb, 1, tbn, 0, [&](const int kk) {
+#pragma unroll
+          for (int j = 0; j < SPK; ++j) scan(h0, acc0, kk * SPK + j);
+        });
+        finish(h0, acc0, t_row0);
+        pend = t_row0 + 32;
+      }
+      const unsigned char *rot = tb;
+      tb = tbn;
+      tbn = tbnn;
+      tbnn = rot;
+    }
+  } else {
   copy_tile(t_lo, 0);
   int buf = 0;
-  for (int t = t_lo; t < t_hi; t += t_step, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
+  for (int t = t_lo; t < t_hi; t += t_step, buf ^= 1) {    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
     __syncthreads();                                   // ... and everyone's; the other buffer's readers are done
     if (t + t_step < t_hi) copy_tile(t + t_step, buf ^ 1);
     if (!wave_live) continue;
@@ -480,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm(const HeadGemmArgs a) {
       finish(h0, acc0, t_row0 + 32 * b);
     }
     pend = t_row0 + 32 * (NB - 1);
+  }
   }
   if (wave_live && pend >= 0) {
 #pragma unroll
@@ -535,8 +613,8 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
       qv[qq][k] = __uint_as_float((uint32_t)b << 16);
     }
     __syncthreads();
-    for (int64_t tl = (int64_t)blockIdx.x * 4 + tid / kWave; a.part + tl * a.n_parts < n_tiles; tl += (int64_t)gridDim.x * 4) {
-      const int64_t t = a.part + tl * a.n_parts;
+    for (int64_t tl = (int64_t)blockIdx.x * 4 + tid / kWave; a.part + tl * max(a.n_parts, 1) < n_tiles; tl += (int64_t)gridDim.x * 4) {
+      const int64_t t = a.part + tl * max(a.n_parts, 1);
       const int64_t c = t * kHeadCTile + ln;
       float s[kGemvQ];
 #pragma unroll

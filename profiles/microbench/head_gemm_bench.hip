@@ -3,12 +3,13 @@
 // Run:   ./head_gemm_bench [N=262144] [KH=256] [stored=1] [reps=3]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
-#include "../../all-pairs-similarity_amd/csrc/apss_head.hpp"
+#include "head_gemm16.hpp"
 
 using namespace apss;
 
@@ -84,6 +85,12 @@ int main(int argc, char **argv) {
   g.res_cap = cap;
   g.counters = ctr;
   g.head_pairs = ctr + 4;
+  g.kt = kh;
+  g.blk = 0;
+  g.part = 0;
+  g.n_parts = 1;
+  const bool m16 = getenv("M16") != nullptr;  // the v_mfma_f32_16x16x32_bf16 form of the kernel
+  const bool clk = getenv("CLK") != nullptr;  // diagnostic instantiation: in-kernel clock (s_memtime / s_memrealtime), M16 + KH 256 only
   double tiles = 0;
   for (int64_t b = 0; b < g.n_qblocks; ++b)
     tiles += stored ? (double)std::min<int64_t>(g.n_ctiles, (b + 1) * kHeadQBlock / ct) : (double)g.n_ctiles;
@@ -92,10 +99,29 @@ int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const dim3 grid((unsigned)((int64_t)g.n_qblocks * g.n_panels));
+  unsigned long long *d_clk = nullptr;
+  if (clk) {
+    CK(hipMalloc(&d_clk, (size_t)grid.x * 16));
+    CK(hipMemset(d_clk, 0, (size_t)grid.x * 16));
+    g.clk = d_clk;
+  }
   for (int r = 0; r < reps + 1; ++r) {
     CK(hipMemset(ctr, 0, 64));
     CK(hipEventRecord(e0, 0));
-    if (kh == 64) hipLaunchKernelGGL(k_head_gemm<64>, grid, dim3(512), 0, 0, g);
+    if (getenv("NW4")) {  // experiment: two independent 4-wave workgroups per CU (256 query slots each, own barriers)
+      HeadGemmArgs g4 = g;
+      g4.n_qblocks = (int32_t)((n + 255) / 256);
+      const dim3 grid4((unsigned)((int64_t)g4.n_qblocks * g4.n_panels));
+      hipLaunchKernelGGL((k_head_gemm<256, true, false, 4>), grid4, dim3(256), 0, 0, g4);
+    } else if (clk) hipLaunchKernelGGL((k_head_gemm16<256, true, true>), grid, dim3(512), 0, 0, g);
+    else if (m16 && kh == 64) hipLaunchKernelGGL(k_head_gemm16<64>, grid, dim3(512), 0, 0, g);
+    else if (m16 && kh == 128) hipLaunchKernelGGL(k_head_gemm16<128>, grid, dim3(512), 0, 0, g);
+    else if (m16 && getenv("NOCOUNT")) hipLaunchKernelGGL((k_head_gemm16<256, false>), grid, dim3(512), 0, 0, g);
+    else if (m16) hipLaunchKernelGGL(k_head_gemm16<256>, grid, dim3(512), 0, 0, g);
+    else if (getenv("PIPE2") && kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, false>), grid, dim3(512), 0, 0, g);
+    else if (getenv("PIPE2") && kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, false>), grid, dim3(512), 0, 0, g);
+    else if (getenv("PIPE2")) hipLaunchKernelGGL((k_head_gemm<256, true, false>), grid, dim3(512), 0, 0, g);
+    else if (kh == 64) hipLaunchKernelGGL(k_head_gemm<64>, grid, dim3(512), 0, 0, g);
     else if (kh == 128) hipLaunchKernelGGL(k_head_gemm<128>, grid, dim3(512), 0, 0, g);
     else if (getenv("NOCOUNT")) hipLaunchKernelGGL((k_head_gemm<256, false>), grid, dim3(512), 0, 0, g);
     else hipLaunchKernelGGL(k_head_gemm<256>, grid, dim3(512), 0, 0, g);
@@ -105,8 +131,20 @@ int main(int argc, char **argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long c[8];
     CK(hipMemcpy(c, ctr, 64, hipMemcpyDeviceToHost));
-    if (r) printf("N=%lld KH=%d stored=%d panels=%lld grid=%u: %.3f ms  %.1f TFLOP/s (%.3f of 2500)  results=%llu positive=%llu\n",
-                  (long long)n, kh, stored, (long long)panels, grid.x, ms, flops / ms / 1e9, flops / ms / 1e9 / 2500.0, c[0], c[4]);
+    if (r) printf("%s N=%lld KH=%d stored=%d panels=%lld grid=%u: %.3f ms  %.1f TFLOP/s (%.3f of 2500)  results=%llu positive=%llu\n",
+                  m16 ? "16x16x32" : "32x32x16", (long long)n, kh, stored, (long long)panels, grid.x, ms, flops / ms / 1e9, flops / ms / 1e9 / 2500.0, c[0], c[4]);
+  }
+  if (clk) {
+    // median over the workgroups that ran a sizeable loop (after `reps` back-to-back launches on random data)
+    std::vector<unsigned long long> h((size_t)grid.x * 2);
+    CK(hipMemcpy(h.data(), d_clk, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    for (size_t i = 0; i < grid.x; ++i)
+      if (h[2 * i + 1] > 1000) mhz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);
+    std::sort(mhz.begin(), mhz.end());
+    if (!mhz.empty())
+      printf("in-kernel clock: median %.0f MHz (p10 %.0f, p90 %.0f) over %zu workgroups\n", mhz[mhz.size() / 2], mhz[mhz.size() / 10],
+             mhz[mhz.size() * 9 / 10], mhz.size());
   }
   return 0;
 }
