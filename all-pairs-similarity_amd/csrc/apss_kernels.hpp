@@ -556,6 +556,17 @@ __global__ void k_tile_min_sub(const float *sub, int64_t n_rows, int32_t cb, flo
   if (threadIdx.x == 0) tile_min[tile] = red[0] > 1.0e38f ? 0.f : red[0];
 }
 
+// inclusive prefix sum over the 64 lanes with DPP (VALU only, no LDS round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1, lanes without a source add 0
+  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2, 3
+  return x;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // probe (IWA:74-111 + CU:98-117 + IWA:93)
 
@@ -892,25 +903,92 @@ __global__ __launch_bounds__(BLOCK) void k_probe(const ProbeArgs a) {
         if (tid == 0) ctr[2] = 0;
       }
     } else {
-      for (int i = tid; i < (cb + BLOCK - 1) / BLOCK * BLOCK; i += BLOCK) {
-        bool ok = false;
-        float sc = 0.f;
-        if (i < cb) {
-          sc = FX ? (float)acci[i] * fxinv : L.acc[i];
-          const int64_t gs = tile_row0 + i;
-          bool touched = (MODE == 2) ? ((L.bitmap[i >> 5] >> (i & 31)) & 1u) : (acci[i] != 0);
-          if (touched && gs < a.n_rows) {
-            const bool self = a.ext_id[gs] == qext;
-            if (!self) my_cands += 1;
-            ok = !self && (FX ? acci[i] >= thr_i : sc >= thr) && (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs] * 0.999999f);
+      // the accumulator scan: candidate i of the tile is a result iff it was touched, is not the query itself and reaches theta
+      auto judge = [&](const int i, float &sc, bool &cand) -> bool {
+        cand = false;
+        sc = 0.f;
+        if (i >= cb) return false;
+        sc = FX ? (float)acci[i] * fxinv : L.acc[i];
+        const int64_t gs = tile_row0 + i;
+        const bool touched = (MODE == 2) ? ((L.bitmap[i >> 5] >> (i & 31)) & 1u) : (acci[i] != 0);
+        if (!touched || gs >= a.n_rows) return false;
+        if (a.ext_id[gs] == qext) return false;
+        cand = true;
+        return (FX ? acci[i] >= thr_i : sc >= thr) && (!a.c_scale || sc >= a.theta * qs * a.c_scale[gs] * 0.999999f);
+      };
+      if (MODE == 2) {
+        // theta <= 0 (the reference's server template ships similarityThreshold = 0): nearly every touched candidate is a
+        // result, so the round's OUTPUT is the work.  One reservation of the global list per workgroup and round -- a ballot
+        // count per (scan step, wave), a scan of those counts by one wave, ONE global atomic -- then every wave writes its
+        // results as a contiguous run.  (One atomic per wave and step on the one list counter, as the sparse-output modes do
+        // it, is serialised at the memory side: 4.5e7 of them were nearly all of the 676 ms of a 60k x 60k join at dim 1024.)
+        constexpr int NWV = BLOCK / kWave;
+        const int n_steps = (cb + BLOCK - 1) / BLOCK;  // <= 32: cb <= 32768
+        uint32_t *const cnt = L.surv;                  // [n_steps][NWV] (the crossing list is not used in this mode)
+        unsigned long long *const masks = reinterpret_cast<unsigned long long *>(L.items);  // [n_steps][NWV] (nor is the work list, by now)
+        const int wvi = tid / kWave;
+        for (int k = 0; k < n_steps; ++k) {
+          float sc;
+          bool cand;
+          const bool ok = judge(k * BLOCK + tid, sc, cand);
+          my_cands += cand ? 1u : 0u;
+          const unsigned long long m = __ballot(ok);
+          if ((tid % kWave) == 0) {
+            cnt[k * NWV + wvi] = (uint32_t)__popcll(m);
+            masks[k * NWV + wvi] = m;  // (the writing pass does not judge again: no second read of the external ids)
           }
         }
+        __syncthreads();
+        if (tid < kWave) {  // n_steps * NWV <= 512 counts: eight per lane
+          const int n_cnt = n_steps * NWV;
+          uint32_t v[8], run = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = tid * 8 + j < n_cnt ? cnt[tid * 8 + j] : 0u;
+            run += v[j];
+          }
+          const uint32_t incl = wave_incl_scan(run);
+          const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+          unsigned long long base = 0;
+          if (tid == 0 && total) base = atomicAdd(&a.counters[kCtrResults], (unsigned long long)total);
+          base = __shfl(base, 0);
+          uint32_t off = incl - run;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (tid * 8 + j < n_cnt) cnt[tid * 8 + j] = off;
+            off += v[j];
+          }
+          if (tid == 0) {
+            L.surv[kSurvCap - 2] = (uint32_t)base;
+            L.surv[kSurvCap - 1] = (uint32_t)(base >> 32);
+          }
+        }
+        __syncthreads();
+        const unsigned long long base = (unsigned long long)L.surv[kSurvCap - 2] | ((unsigned long long)L.surv[kSurvCap - 1] << 32);
+        for (int k = 0; k < n_steps; ++k) {
+          const int i = k * BLOCK + tid;
+          const unsigned long long m = masks[k * NWV + wvi];
+          const bool ok = (m >> (tid % kWave)) & 1ull;
+          const uint64_t o = base + cnt[k * NWV + wvi] + (uint64_t)__popcll(m & ((1ull << (tid % kWave)) - 1ull));
+          if (ok && o < a.res_cap) {
+            a.res_q[o] = q;
+            a.res_c[o] = (int32_t)(tile_row0 + i);
+            a.res_s[o] = FX ? (float)acci[i] * fxinv : L.acc[i];
+          }
+        }
+      } else {
+      for (int i = tid; i < (cb + BLOCK - 1) / BLOCK * BLOCK; i += BLOCK) {
+        float sc;
+        bool cand;
+        const bool ok = judge(i, sc, cand);
+        my_cands += cand ? 1u : 0u;
         const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
         if (ok && o < a.res_cap) {
           a.res_q[o] = q;
           a.res_c[o] = (int32_t)(tile_row0 + i);
           a.res_s[o] = sc;
         }
+      }
       }
       __syncthreads();
     }
@@ -974,16 +1052,6 @@ __device__ __forceinline__ int64_t uniform64(int64_t x) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-// inclusive prefix sum over the 64 lanes with DPP (VALU only, no LDS round trips)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1, lanes without a source add 0
-  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
-  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
-  x += (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1, 3
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2, 3
-  return x;
-}
 
 // LONGCAP: long segments per round kept in the workgroup list (more stay with their wave); SURVCAP: threshold
 // crossings per round kept in LDS (more: the round falls back to scanning the accumulators)

@@ -70,10 +70,12 @@ def main():
     ap.add_argument("--messages", type=int, default=50, help="benchmark.totalMessageCount")
     ap.add_argument("--interval-ms", type=float, default=50.0, help="benchmark.writeBatchingDuration (0 = back to back)")
     ap.add_argument("--zipf", type=float, default=0.0, help="term distribution of the synthetic vectors")
+    ap.add_argument("--theta", type=float, default=None, help="override the shape's similarityThreshold (0: what "
+                    "conf/app_server_template.conf:17 ships -- every vector sharing a term is an answer)")
     a = ap.parse_args()
     from apss import synth
     shp = SHAPES[a.shape]
-    dim, theta, nnz = shp["dim"], shp["theta"], min(shp["nnz"], shp["dim"])
+    dim, theta, nnz = shp["dim"], shp["theta"] if a.theta is None else a.theta, min(shp["nnz"], shp["dim"])
     rp, idx, val = synth.make_vectors(a.preload, dim, nnz, a.zipf, seed=5)
     out = {"metric": "single-vector IndexData response time (ms), LoadGenerator-style", "messages": a.messages,
            "interval_ms": a.interval_ms, "index_size": a.preload,
