@@ -54,11 +54,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   constexpr int CH = 16, LPC = CH / 2, GPW = kWave / LPC, WIN = GPW * U;
   constexpr int SLOTS = 2 * WIN < 48 ? 2 * WIN : (WIN > 48 ? WIN : 48);  // strip slots per wave and round (>= WIN)
   static_assert(SLOTS >= WIN, "the register window reads the first WIN slots of a strip");
+  // A strip is stored GROUP-major: slot sl = u * GPW + g (window step u, lane group g) lives at entry g * GS + u, so that the
+  // entries a lane group needs for two consecutive steps are adjacent and one ds_read_b128 fetches both (the adding waves'
+  // strip reads were 23 % of the LDS instructions of a C3 round; GS even: 16-B alignment of every pair)
+  // (the 1024-thread kernel's LDS is full to within a few hundred bytes: no padding there, pairs only where GS is even anyway)
+  constexpr int GS = BLOCK > 512 ? SLOTS / GPW : ((SLOTS / GPW) + 1) & ~1;  // entries per lane group
+  constexpr int SSZ = GPW * GS;                 // entries per strip
+  static_assert(GPW == 8 && SLOTS % GPW == 0, "slot <-> (step, group) by shifts");
   constexpr int kLongLen = kLongLenW;
   constexpr int CBMAX = WIDE ? 131072 : (BLOCK <= 512 && !ACC8 ? 32768 : 65536);
   constexpr int APW = 32 / (int)ABITS;
   __shared__ __attribute__((aligned(16))) uint32_t acc[CBMAX / APW + kWave];  // (+ one spare word per lane: idle lanes add there)
-  __shared__ uint2 strips[3 * NS * SLOTS + kWave];  // [3][NS][SLOTS] {byte offset of the chunk's first posting, weight bits} (+ one spare entry per lane)
+  __shared__ __attribute__((aligned(16))) uint2 strips[3 * NS * SSZ + kWave];  // [3][NS][GPW][GS] {byte offset of the chunk's first posting, weight bits} (+ one spare entry per lane)
   __shared__ uint2 longs[3 * LONGCAP];
   __shared__ float long_w[3 * LONGCAP];
   __shared__ uint2 facts[4];  // per ring slot: {chunks of the round, bit 0: flagged for the direct sweep, bits 1..: long segments}
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // index through a DPP move, and every lane writes at most two descriptors -- to the strip, or to its own spare entry when
   // it has none (a select on the address, not an exec mask).  Everything unusual -- a long segment, a term of more than
   // 2 G chunks, a round that does not fit -- takes one branch.
-  uint2 *const spare_item = strips + 3 * NS * SLOTS + ln;
+  uint2 *const spare_item = strips + 3 * NS * SSZ + ln;
   auto flatten = [&](const Seg &g, const int ring) {
     uint32_t len = g.len;
     my_visits += sub == 0u ? len : 0u;
@@ -178,13 +185,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     if (LOGG == 2) j0 = (uint32_t)__builtin_amdgcn_update_dpp((int)j0, (int)j0, 0x00, 0xf, 0xf, false);       // quad_perm [0,0,0,0]
     else if (LOGG == 1) j0 = (uint32_t)__builtin_amdgcn_update_dpp((int)j0, (int)j0, 0xa0, 0xf, 0xf, false);  // quad_perm [0,0,2,2]
     const uint32_t wbits = __float_as_uint(cxs * g.w);
-    uint2 *const st = strips + ring * (NS * SLOTS);
+    uint2 *const st = strips + ring * (NS * SSZ);
     auto put = [&](const uint32_t k) {
       // chunk j of the round -> adding wave j % A, slot j / A ((j + 0.5) / A is at least 1 / 2A away from an integer:
       // the float quotient truncates exactly for j < 2^16)
       const uint32_t j = min(j0 + k, (uint32_t)CAP - 1u);  // (a round that does not fit is flagged below; keep the store inside the strips)
       const uint32_t sl = (uint32_t)(((float)j + 0.5f) * rcpA);
-      uint2 *const dst = k < nch ? st + (j - sl * (uint32_t)A) * SLOTS + sl : spare_item;
+      uint2 *const dst = k < nch ? st + (j - sl * (uint32_t)A) * SSZ + (sl & 7u) * GS + (sl >> 3) : spare_item;
       *dst = make_uint2((g.s + k * CH) * 4u, wbits);
     };
     // chunks per term written without the loop: 8 with four lanes per term (two writes each), 6 with two, 3 with one
@@ -214,9 +221,19 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   struct StripRead { uint2 fc; uint2 it[U]; };
   auto strip_read = [&](StripRead &sr, const int ring, const int rank) {
     sr.fc = facts[ring];
-    const uint2 *const st = strips + (ring * NS + rank) * SLOTS;
+    const uint2 *const st = strips + (ring * NS + rank) * SSZ + (ln / LPC) * GS;
+    if constexpr (GS % 2 == 0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) sr.it[u] = st[u * GPW + ln / LPC];
+      for (int u = 0; u + 1 < U; u += 2) {
+        const uint4 two = *reinterpret_cast<const uint4 *>(st + u);
+        sr.it[u] = make_uint2(two.x, two.y);
+        sr.it[u + 1] = make_uint2(two.z, two.w);
+      }
+      if (U & 1) sr.it[U - 1] = st[U - 1];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) sr.it[u] = st[u];
+    }
   };
   // second half: every LPC lanes take one chunk of the strip and start its posting load.  VALU only -- the one value the
   // next round branches on (is it more than a register window?) goes to the scalar unit here, a round before its use.
@@ -411,10 +428,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
         const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0.flags);
         const int mc = (int)(w0.info & kCountMask);
         if (mc > WIN) {  // chunks past the register window: straight from this wave's strip
-          const uint2 *const st = strips + (r0 * NS + rank) * SLOTS;
+          const uint2 *const st = strips + (r0 * NS + rank) * SSZ;
           for (int c0 = WIN; c0 < mc; c0 += GPW) {
             const int c = c0 + ln / LPC;
-            const uint2 it = st[min(c, SLOTS - 1)];
+            const int cc = min(c, SLOTS - 1);
+            const uint2 it = st[(cc & 7) * GS + (cc >> 3)];
             const apss_u32x2 two = __builtin_amdgcn_raw_buffer_load_b64(rs_po, c < mc ? it.x + lo * 8u : kOob, 0, 0);
             visit2(two.x, two.y, __uint_as_float(it.y));
           }

@@ -287,8 +287,9 @@ struct HeadGemmArgs {
   unsigned long long *clk;         // diagnostic kernel of the microbenchmark only: per workgroup {shader cycles, 100-MHz ticks}
 };
 
-template <int KH, bool COUNT = true, bool PIPE3 = true, int NW = 8>
+template <int KH, bool COUNT = true, int NBUF = 3, int NW = 8>
 __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) {
+  constexpr bool PIPE3 = NBUF >= 3;           // NBUF tile buffers in LDS: 2 = barrier at the tile boundary, >= 3 = barrier in mid-tile
   constexpr int QB = 64 * NW;                 // query slots per workgroup (kHeadQBlock in the library; 256 in an experiment of the microbenchmark)
   constexpr int KS = KH / 16;                 // k-steps of the 32x32x16 MFMA
   constexpr int SPK = 16 / KS;                // epilogue scan steps (2 accumulators each) per k-step of the other half
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   constexpr int PPW = PIECES / NW;            // pieces per wave
   constexpr int PF = 2;                       // B fragments requested ahead of the MFMAs that use them
   static_assert(PIECES % NW == 0, "every wave copies the same number of pieces");
-  __shared__ __attribute__((aligned(1024))) unsigned char ldsb[(PIPE3 ? 3 : 2) * TILEB];
+  __shared__ __attribute__((aligned(1024))) unsigned char ldsb[NBUF * TILEB];
   __shared__ float scratch[NW * 16 * kWave];  // reporting path only: one 32 x 32 accumulator block per wave
 
   const int tid = threadIdx.x;
@@ -488,15 +489,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
       }
     };
     static_assert(KS % PF == 0 && KS >= PF, "the prefetch queue's slots line up across halves");
+    // prologue: the first NBUF - 1 tiles are requested; the first must have landed (loads complete in issue order)
     copy_tile(t_lo, 0);
-    if (t_lo + t_step < t_hi) {
-      copy_tile(t_lo + t_step, 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");  // the first tile's pieces (loads complete in issue order)
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    int ahead = 0;  // tiles requested beyond the current one
+#pragma unroll
+    for (int j = 1; j < NBUF - 1; ++j)
+      if (t_lo + j * t_step < t_hi) {
+        copy_tile(t_lo + j * t_step, j);
+        ++ahead;
+      }
+    if (ahead == NBUF - 2 && NBUF > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const unsigned char *tb = ldsb, *tbn = ldsb + TILEB, *tbnn = ldsb + 2 * TILEB;
+    int bi = 0;  // buffer of the current tile
+    auto buf_of = [&](const int k) { return ldsb + ((bi + k) % NBUF) * TILEB; };
+    const unsigned char *tb = buf_of(0), *tbn = buf_of(1);
     if (wave_live) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) bq[j] = ldfrag(tb, 0, j);
@@ -514,9 +521,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
           mma_run(acc0, tb, 0, tb, 1, [&](const int) {});
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t + 1 have landed
+      // this wave's pieces of tile t + 1 have landed (the tiles requested after it may still be in flight: counted wait)
+      if (NBUF > 3 && t + (NBUF - 2) * t_step < t_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF > 3 ? NBUF - 3 : 0) * PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                   // ... and everyone's; nobody reads tile t - 1 any more
-      if (t + 2 * t_step < t_hi) copy_tile(t + 2 * t_step, (int)((tbnn - ldsb) / TILEB));
+      if (t + (NBUF - 1) * t_step < t_hi) copy_tile(t + (NBUF - 1) * t_step, (bi + NBUF - 1) % NBUF);  // into tile t - 1's buffer
       if (wave_live) {
         mma_run(acc1, tb, 1, tbn, 0, [&](const int kk) {
 #pragma unroll
@@ -525,10 +534,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
         finish(h0, acc0, t_row0);
         pend = t_row0 + 32;
       }
-      const unsigned char *rot = tb;
-      tb = tbn;
-      tbn = tbnn;
-      tbnn = rot;
+      bi = (bi + 1) % NBUF;
+      tb = buf_of(0);
+      tbn = buf_of(1);
     }
   } else {
   copy_tile(t_lo, 0);

@@ -1076,10 +1076,10 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
       const dim3 grid((unsigned)((int64_t)g.n_qblocks * g.n_panels));
       // (three tile buffers + the barrier in mid-tile pay at KH = 256 only: 0.69 vs 0.67 of the bf16 peak; narrow blocks are
       // bound by their epilogue and lose with it: profiles/r03_head_gemm.md)
-      if (b > 0) hipLaunchKernelGGL((k_head_gemm<256, false, true>), grid, dim3(512), 0, h->stream, g);
-      else if (kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, false>), grid, dim3(512), 0, h->stream, g);
-      else if (kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, false>), grid, dim3(512), 0, h->stream, g);
-      else hipLaunchKernelGGL((k_head_gemm<256, true, true>), grid, dim3(512), 0, h->stream, g);
+      if (b > 0) hipLaunchKernelGGL((k_head_gemm<256, false, 3>), grid, dim3(512), 0, h->stream, g);
+      else if (kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, 2>), grid, dim3(512), 0, h->stream, g);
+      else if (kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, 2>), grid, dim3(512), 0, h->stream, g);
+      else hipLaunchKernelGGL((k_head_gemm<256, true, 3>), grid, dim3(512), 0, h->stream, g);
     }
   }
   g.n_qblocks = (int32_t)all_qblocks;

@@ -122,6 +122,17 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
 PROBE_TRAFFIC = os.path.join(ROOT, "profiles", "r03_probe_traffic.json")
 
 
+def csrc_sha256():
+    """content hash of the library's sources (what profiles/collect_r03.sh records beside the counters it collects)"""
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "all-pairs-similarity_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))) + sorted(glob.glob(os.path.join(csrc, "*.hpp"))) + [os.path.join(ROOT, "include", "apss.h")]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def profile_quote(workload, n_override, tile_rows, alg_bytes, kernel):
     """HBM-side bytes and SQ counters of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
     committed summary of the same command (profiles/collect_r03.sh -> profiles/r03_probe_traffic.json) is quoted -- only
@@ -136,8 +147,10 @@ def profile_quote(workload, n_override, tile_rows, alg_bytes, kernel):
     counted_on = ent.get("detail", {}).get("kernels", {}).get("filter", {}).get("kernel", "")
     if not kernel or ("apss::" + kernel) not in counted_on:
         return None
+    if ent.get("csrc_sha256") != csrc_sha256():  # the kernels have changed since the counters were collected
+        return None
     ent = dict(ent)
-    ent["counted_on"] = {"kernel": counted_on, "csrc_git": tj.get("csrc_git")}
+    ent["counted_on"] = {"kernel": counted_on, "csrc_sha256": ent.get("csrc_sha256")}
     return ent
 
 

@@ -112,15 +112,16 @@ int main(int argc, char **argv) {
       HeadGemmArgs g4 = g;
       g4.n_qblocks = (int32_t)((n + 255) / 256);
       const dim3 grid4((unsigned)((int64_t)g4.n_qblocks * g4.n_panels));
-      hipLaunchKernelGGL((k_head_gemm<256, true, false, 4>), grid4, dim3(256), 0, 0, g4);
+      hipLaunchKernelGGL((k_head_gemm<256, true, 2, 4>), grid4, dim3(256), 0, 0, g4);
     } else if (clk) hipLaunchKernelGGL((k_head_gemm16<256, true, true>), grid, dim3(512), 0, 0, g);
     else if (m16 && kh == 64) hipLaunchKernelGGL(k_head_gemm16<64>, grid, dim3(512), 0, 0, g);
     else if (m16 && kh == 128) hipLaunchKernelGGL(k_head_gemm16<128>, grid, dim3(512), 0, 0, g);
     else if (m16 && getenv("NOCOUNT")) hipLaunchKernelGGL((k_head_gemm16<256, false>), grid, dim3(512), 0, 0, g);
     else if (m16) hipLaunchKernelGGL(k_head_gemm16<256>, grid, dim3(512), 0, 0, g);
-    else if (getenv("PIPE2") && kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, false>), grid, dim3(512), 0, 0, g);
-    else if (getenv("PIPE2") && kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, false>), grid, dim3(512), 0, 0, g);
-    else if (getenv("PIPE2")) hipLaunchKernelGGL((k_head_gemm<256, true, false>), grid, dim3(512), 0, 0, g);
+    else if (getenv("PIPE4")) hipLaunchKernelGGL((k_head_gemm<256, true, 4>), grid, dim3(512), 0, 0, g);
+    else if (getenv("PIPE2") && kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, 2>), grid, dim3(512), 0, 0, g);
+    else if (getenv("PIPE2") && kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, 2>), grid, dim3(512), 0, 0, g);
+    else if (getenv("PIPE2")) hipLaunchKernelGGL((k_head_gemm<256, true, 2>), grid, dim3(512), 0, 0, g);
     else if (kh == 64) hipLaunchKernelGGL(k_head_gemm<64>, grid, dim3(512), 0, 0, g);
     else if (kh == 128) hipLaunchKernelGGL(k_head_gemm<128>, grid, dim3(512), 0, 0, g);
     else if (getenv("NOCOUNT")) hipLaunchKernelGGL((k_head_gemm<256, false>), grid, dim3(512), 0, 0, g);
