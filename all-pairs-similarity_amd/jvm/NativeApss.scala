@@ -15,4 +15,10 @@ object NativeApss {
   @native def submit(h: Long, mode: Int, rowptr: Array[Long], indices: Array[Int], values: Array[Double],
                      ids: Array[Long]): Long
   @native def fetch(h: Long, count: Long, outQ: Array[Long], outC: Array[Long], outScore: Array[Float]): Int
+  /** term-sharded deployments (one worker per GPU owning a term range): the join's dense-head block, the same terms on
+    * every shard, worker `part` of `nParts` multiplying its share of the candidate tiles (include/apss.h,
+    * apss_set_head_terms); empty handle only.  Returns 0 or a negative status */
+  @native def setHeadTerms(h: Long, terms: Array[Int], part: Int, nParts: Int): Int
+  /** the block's terms, chosen by the library or set by setHeadTerms (what one shard's policy decided is what its peers are given) */
+  @native def headTerms(h: Long): Array[Int]
 }

@@ -110,5 +110,32 @@ JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_fetch(JNIEnv *env, jclass cls,
   free(q);
   return rc;
 }
+
+JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_setHeadTerms(JNIEnv *env, jclass cls, jlong h, jintArray terms, jint part,
+                                                               jint nParts) {
+  (void)cls;
+  const jsize n = (*env)->GetArrayLength(env, terms);
+  jint *t = (jint *)malloc(sizeof(jint) * (size_t)(n > 0 ? n : 1));
+  if (!t) return APSS_E_NOMEM;
+  (*env)->GetIntArrayRegion(env, terms, 0, n, t);
+  const int32_t rc = (*env)->ExceptionCheck(env) ? APSS_E_INVALID : apss_set_head_terms(H(h), n, (const int32_t *)t, part, nParts);
+  free(t);
+  return rc;
+}
+
+JNIEXPORT jintArray JNICALL Java_cpslab_gpu_NativeApss_headTerms(JNIEnv *env, jclass cls, jlong h) {
+  (void)cls;
+  int32_t n = 0;
+  if (apss_get_head_terms(H(h), 0, 0, &n) != APSS_OK) return 0;
+  int32_t *t = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+  if (!t) return 0;
+  jintArray out = 0;
+  if (apss_get_head_terms(H(h), n, t, &n) == APSS_OK) {
+    out = (*env)->NewIntArray(env, n);
+    if (out) (*env)->SetIntArrayRegion(env, out, 0, n, (const jint *)t);
+  }
+  free(t);
+  return out;
+}
 #endif
 #endif

@@ -98,7 +98,7 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
     opt = oracle.selfjoin_sample(1, cfg["dim"], cfg["theta"], rp, idx, val, 0, min(n, sample * 20), cores)
     all_cores = None
     if avail > cores:  # "T = all host cores, core count printed": the same port on every core the process may use
-        s_all = int(min(n, sample * avail // cores))
+        s_all = sample  # (the same sample: a GPU box may expose every core of the machine while the run is entitled to a share of them)
         ra = oracle.selfjoin_sample(0, cfg["dim"], cfg["theta"], rp, idx, val, 0, s_all, avail)
         all_cores = {"value": ra["cand_pairs"] / ra["seconds"], "cores": avail,
                      "sample": "first %d queries, %.1f s, %d threads" % (s_all, ra["seconds"], avail)}
@@ -243,7 +243,8 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
                     "candidate_pairs_note": "max(pairs sharing a tail term, pairs sharing a head term): a lower bound of "
                                             "the distinct pairs scored (a pair sharing both kinds is scored by both filters)"})
         head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16)" % (
-                         min(256, st["head_terms"]), " x %d blocks" % ((st["head_terms"] + 255) // 256) if st["head_terms"] > 256 else ""),
+                         min(256, st["head_terms"]), " x 2 blocks (256 terms with a column each + %d terms folded into 256 columns)"
+                         % (st["head_terms"] - 256) if st["head_terms"] > 256 else ""),
                      "achieved": flops / head_s / 1e12 if head_s > 0 else None, "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / head_s / 1e12 / MFMA_BF16_PEAK_TFLOPS if head_s > 0 else None,
                      "traffic": None,
@@ -345,7 +346,7 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
             nt = sj.last["head_terms"]
             kh = 64 if nt <= 64 else (128 if nt <= 128 else 256)
             head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16), candidate tiles t %% %d == rank" % (
-                             kh, " x %d blocks" % ((nt + 255) // 256) if nt > 256 else "", sj.T),
+                             kh, " x 2 blocks (256 + %d folded terms)" % (nt - 256) if nt > 256 else "", sj.T),
                          "achieved": head_flops / (hm * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s (per GPU: the slowest rank's kernel and that rank's flops)",
                          "frac": head_flops / (hm * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None}

@@ -28,5 +28,7 @@ struct JNINativeInterface_ {
   void (*SetLongArrayRegion)(JNIEnv *, jlongArray, jsize, jsize, const jlong *);
   void (*SetFloatArrayRegion)(JNIEnv *, jfloatArray, jsize, jsize, const jfloat *);
   jboolean (*ExceptionCheck)(JNIEnv *);
+  jintArray (*NewIntArray)(JNIEnv *, jsize);
+  void (*SetIntArrayRegion)(JNIEnv *, jintArray, jsize, jsize, const jint *);
 };
 #endif
