@@ -259,6 +259,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   // FIXED ROLES: waves 0 .. F-1 stage every round and never add, waves F .. NW-1 add every round and never stage.  The two
   // kinds run their own loops (same two barriers per round): no per-round role arithmetic on the scalar unit, and the
   // compiler allocates registers for one job at a time.
+  // BARRIER PAIRING.  The two sides execute `__syncthreads()` at different places of the source: HIP only promises a barrier
+  // for one textual call reached by all threads; gfx950's s_barrier counts arriving WAVES, whichever s_barrier instruction
+  // they execute, so what must hold -- and does, by construction -- is that every wave of the workgroup executes the same
+  // NUMBER of barriers: 2 before the loops (the prologue below, executed by all), then exactly 2 per query v in [v0, v1) on
+  // both sides (staging: one iteration per v; adding: the loop steps by two and leaves after round v when v + 1 >= v1, so an
+  // odd count ends after its last round), then the epilogue's.  No path inside a round skips a barrier (`rare` rounds clear
+  // the whole tile between the same two).  tests/test_gpu_even.py::test_chunk_shapes_pin_the_barrier_pairing runs chunks of
+  // one, two and three queries, a short last chunk and one- and two-row batches.
   // (Tried: a staging wave taking TWO sets of terms per round -- half the staging waves, one more adding wave; C3 7 x 5
   // window steps instead of 6 x 6.  The second set's registers tipped the kernel into scratch: 140 vs 101 ms.)
   const bool stager = wv < F;

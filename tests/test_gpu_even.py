@@ -88,3 +88,26 @@ def test_thin_kernel_under_the_shard_rule(oracle):
     assert_same_pairs(to_map(q, c, s), want, theta)
     assert sum(e.stats["thin_launches"] for e in engines) > 0, [e.stats["thin_launches"] for e in engines]
     assert sum(e.stats["posting_visits"] for e in engines) == int((np.bincount(idx, minlength=dim).astype(np.int64) ** 2).sum())
+
+
+@pytest.mark.parametrize("n,chunks", [(2047, 2047), (2047, 1024), (2048, 683), (1000, 334), (777, 1), (2, 2), (1, 1)])
+def test_chunk_shapes_pin_the_barrier_pairing(oracle, monkeypatch, n, chunks):
+    """k_probe_even's staging and adding waves run DIFFERENT loops around the same two barriers per round (apss_even.hpp): the
+    counts match by construction -- one iteration per query of the workgroup's chunk on both sides, the adding waves' loop
+    unrolled by two with an exit after an odd last round.  Pinned here on the shapes where a mismatch would hang or corrupt:
+    chunks of ONE query (v1 - v0 = 1: the adders break after their first round), of two and three (even / odd), a short
+    last chunk, one chunk holding everything, and batches of one and two rows"""
+    from apss import synth
+    from apss.engine import ApssIndex
+    monkeypatch.setenv("APSS_DEBUG", "chunks=%d" % chunks)
+    dim, nnz, theta = 900, 10, 0.6
+    rp, idx, val = synth.make_vectors(max(n, 2), dim, nnz, 0.0, seed=31 + n, dup_frac=0.2)
+    rp, idx, val = rp[:n + 1], idx[:rp[n]], val[:rp[n]]
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    with ApssIndex(dim, theta, head_terms=-1) as ix:
+        got = to_map(*ix.insert_and_query(np.arange(n, dtype=np.int64), rp, idx, val))
+        st = ix.stats()
+    assert_same_pairs(got, want, theta)
+    if n > 100:
+        assert st["probe_kernel"].startswith("k_probe_even<"), st["probe_kernel"]
+        assert len(want) > 20
