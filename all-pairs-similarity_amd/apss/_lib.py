@@ -34,7 +34,7 @@ class Stats(C.Structure):
                 ("filter_survivors", C.c_int64), ("rescore_ms", C.c_double),
                 ("head_terms", C.c_int64), ("head_pairs", C.c_int64), ("head_survivors", C.c_int64),
                 ("head_ms", C.c_double), ("head_flops", C.c_double), ("thin_launches", C.c_int64),
-                ("downgrades", C.c_uint32), ("reserved0", C.c_uint32), ("probe_kernel", C.c_char * 96)]
+                ("downgrades", C.c_uint32), ("head_columns", C.c_uint32), ("probe_kernel", C.c_char * 96)]
 
 
 def build_sources():

@@ -121,7 +121,7 @@ class ApssIndex:
     def stats(self):
         st = _lib.Stats()
         self._chk(self._L.apss_stats_get(self._h, C.byref(st)))
-        d = {k: getattr(st, k) for k, _ in _lib.Stats._fields_ if k != "reserved0"}
+        d = {k: getattr(st, k) for k, _ in _lib.Stats._fields_}
         d["probe_kernel"] = d["probe_kernel"].decode()
         return d
 

@@ -83,7 +83,7 @@ __host__ __device__ __forceinline__ int64_t head_chunk_off(int64_t row, int chun
   return (((row >> 6) * (kh / 8) + chunk) * kHeadCTile + (row & 63)) * 8;
 }
 constexpr int kHeadBlock = 256;      // columns per block of a two-block head
-constexpr int kHeadMaxBlocks = 2;    // block 0: one column per term; block 1: the further terms folded into 256 columns
+constexpr int kHeadMaxBlocks = 2;    // block 0: one column per term; block 1: the further terms folded into 128 or 256 columns
 constexpr int kHeadMaxFold = 31;     // terms per column of the folded block at most: heads of up to 256 * 32 = 8192 terms
 
 struct HeadPackArgs {
@@ -275,7 +275,8 @@ struct HeadGemmArgs {
   int32_t n_qblocks, n_panels, n_ctiles;  // n_ctiles: candidate tiles of head_tile_rows(KH) rows
   int32_t part, n_parts;  // this launch multiplies the candidate tiles t with t % n_parts == part (the block of a term-sharded
                           // join is cut over the GPUs by candidate row: 64-row tiles dealt round-robin; 0, 1: every tile)
-  int32_t kt, blk;        // total width of a W row (= KH for a single block) and which block of KH terms this launch multiplies
+  int32_t kt, chunk0;     // total width of a W row (= KH for a single block) and the first 16-B chunk, inside a row, of the block of
+                          // KH columns this launch multiplies (0 for the first block, 32 for the folded block behind 256 columns)
   int64_t qblock0;      // first query block's first slot (a multiple of 512)
   const int64_t *q_ext, *c_ext;
   float thr;
@@ -295,7 +296,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   constexpr int SPK = 16 / KS;                // epilogue scan steps (2 accumulators each) per k-step of the other half
   static_assert(SPK * KS == 16, "KH is 64, 128 or 256");
   constexpr int ROWB = KH * 2;                // bytes per row
-  constexpr int CPR = KH / 8;                 // 16-B chunks per row
   constexpr int SUB = 1;                      // 64-row sub-tiles per LDS tile (32-KB tiles at KH < 256, SUB = 256 / KH, measured
   constexpr int CT = kHeadCTile * SUB;        //   slower: narrow blocks are bound by the epilogue, not by the barrier)
   constexpr int NB = CT / 32;                 // 32-candidate column blocks per tile
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
     const bool ok = row >= 0 && row < a.nq && s < a.wq_rows;
     wave_live |= ok;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq) + ((ok ? wslot0 : 0) / kHeadCTile) * (int64_t)(a.kt / 8 * kHeadCTile) +
-                       (int64_t)a.blk * (CPR * kHeadCTile) + 32 * m + r;
+                       (int64_t)a.chunk0 * kHeadCTile + 32 * m + r;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   // 1-KiB pieces (= chunks) w * PPW .. , lane l the 16 bytes of row l ----
   auto copy_tile = [&](const int t, const int buf) {
     const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * ((int64_t)kHeadCTile * a.kt * 2) +
-                                (int64_t)a.blk * TILEB + ln * 16;
+                                (int64_t)a.chunk0 * (kHeadCTile * 16) + ln * 16;
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
       __builtin_amdgcn_global_load_lds(
@@ -590,7 +590,7 @@ struct HeadGemvArgs {
   int64_t q_slot_base;
   int32_t nq;
   int32_t kh;             // width of the block this launch multiplies (<= 256)
-  int32_t kt, blk;        // total width of a W row, block index (as in HeadGemmArgs)
+  int32_t kt, chunk0;     // total width of a W row, first chunk of the block (as in HeadGemmArgs)
   int32_t part, n_parts;  // as in HeadGemmArgs
   const int64_t *q_ext, *c_ext;
   float thr;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
     __syncthreads();
     for (int i = tid; i < nqq * a.kh; i += blockDim.x) {
       const int qq = i / a.kh, k = i % a.kh;
-      const uint16_t b = a.Wq[head_chunk_off(qs0 + q0 + qq, a.blk * (kHeadBlock / 8) + (k >> 3), a.kt) + (k & 7)];
+      const uint16_t b = a.Wq[head_chunk_off(qs0 + q0 + qq, a.chunk0 + (k >> 3), a.kt) + (k & 7)];
       qv[qq][k] = __uint_as_float((uint32_t)b << 16);
     }
     __syncthreads();
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
       float s[kGemvQ];
 #pragma unroll
       for (int qq = 0; qq < kGemvQ; ++qq) s[qq] = 0.f;
-      const uint4 *tp = reinterpret_cast<const uint4 *>(a.Wc) + t * (int64_t)(a.kt / 8 * kHeadCTile) + (int64_t)a.blk * (kHeadBlock / 8 * kHeadCTile) + ln;
+      const uint4 *tp = reinterpret_cast<const uint4 *>(a.Wc) + t * (int64_t)(a.kt / 8 * kHeadCTile) + (int64_t)a.chunk0 * kHeadCTile + ln;
       for (int ch = 0; ch < cpr; ++ch) {
         const uint4 v = tp[ch * kHeadCTile];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};

@@ -55,6 +55,7 @@ struct DebugCfg {
   bool no_even = false;        // no_even        the filter stages every round on all waves (k_probe_coarse), never on F of them (k_probe_even)
   int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
   bool bank_order = false;     // bank_order     experiment: bank-aware posting order inside short segments (k_seg_bank_order)
+  int fold_w = 0;              // fold_w=N       columns of the dense head's folded block (128 | 256)
 };
 
 DebugCfg parse_debug_env() {
@@ -91,6 +92,7 @@ DebugCfg parse_debug_env() {
     else if (key == "flat_group") d.flat_group = (int)val;
     else if (key == "seg_align") d.seg_align = val;
     else if (key == "bank_order") d.bank_order = val != 0;
+    else if (key == "fold_w") d.fold_w = val;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -174,6 +176,7 @@ struct apss_handle {
   // dense-head block (apss_head.hpp): the KH most frequent terms live in W instead of the inverted index
   int32_t head_k = 0;                 // 0: no block
   bool head_fixed = false;            // the block's terms were set through apss_set_head_terms: no policy, kept across apss_clear
+  int32_t head_fold_w = 256;          // columns of the folded block (128 | 256)
   bool head_longseg = false;          // term shard with a block: its tail still has segments too long for the thin-round kernel (a
                                       // hint kept across apss_clear: the next first build goes straight to the layout that serves them)
   int32_t head_part = 0, head_parts = 1;  // this handle multiplies the candidate tiles t % head_parts == head_part of the block
@@ -545,16 +548,23 @@ constexpr int64_t kTailMaxRows = 4096;   // rows that may wait outside the tile 
 constexpr int64_t kTailMaxBatch = 256;   // a batch larger than this extends the index right away
 constexpr int64_t kTailMaxPairs = 1 << 22;  // (queries x tail rows) a probe scores directly; beyond it the tail is folded in first
 constexpr int32_t kHeadMaxTerms = kHeadBlock * (1 + kHeadMaxFold);   // 256 terms with a column each + 256 columns of kHeadMaxFold terms
-inline int32_t head_width(int32_t n_terms) {  // width of a W row holding n_terms head terms
-  return n_terms <= 64 ? 64 : (n_terms <= 128 ? 128 : (n_terms <= 256 ? 256 : 512));
+// width of a W row holding n_terms head terms: one block of 64 | 128 | 256 columns, or 256 + a folded block of fold_w columns
+inline int32_t head_width(int32_t n_terms, int32_t fold_w) {
+  return n_terms <= 64 ? 64 : (n_terms <= 128 ? 128 : (n_terms <= 256 ? 256 : kHeadBlock + fold_w));
 }
 // column of the i-th head term (most frequent first): the first 256 get a column each, the others fold into the second block
-inline int32_t head_column(int32_t i) { return i < kHeadBlock ? i : kHeadBlock + (i - kHeadBlock) % kHeadBlock; }
+inline int32_t head_column(int32_t i, int32_t fold_w) { return i < kHeadBlock ? i : kHeadBlock + (i - kHeadBlock) % fold_w; }
 constexpr int64_t kHeadMinRows = 16384;  // below this a join is over before a GEMM pays for its set-up
 constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse filter (measured, C3)
 // seconds per (query, candidate) element of the head contraction, block width 64 / 128 / 256 (measured on random rows,
 // profiles/r02_head_gemm.md: 1.65 PFLOP/s at 256; narrower blocks are bound by the epilogue's scan, not by the MFMAs)
 constexpr double kHeadDenseCost[4] = {1.5e-13, 1.9e-13, 3.1e-13, 6.2e-13};  // (last: two blocks of 256 = 256 terms + a folded block)
+// seconds per element a folded block of 128 columns saves over one of 256 (k_head_gemm<128> vs <256>; measured on power-law
+// C5 at N = 2M: 1259 -> 1024 ms per 2e12 elements of a stored batch)
+constexpr double kHeadFold128Gain = 1.2e-13;
+// ... and seconds per pair it passes in excess (measured: C3 with Zipf(1) terms, 5.6e6 more survivors, + 5 ms of reporting,
+// de-duplication and re-scoring; doubled)
+constexpr double kHeadFoldSurvivorCost = 2.0e-9;
 constexpr double kHeadFoldMaxRowTerms = 64.0;  // terms of the folded block a row may hold on average (chance pairs collide in m^2 / 256 columns)
 constexpr double kHeadSurvivorCost = 1.0e-8;  // seconds per element the dense filter passes on (report + de-dup + exact re-score)
 
@@ -729,7 +739,7 @@ int32_t choose_head(apss_handle *h, bool *changed) {
   double best_gain = 0.0;  // seconds per N^2 pairs the chosen block is expected to save
   double gain256 = 0.0;    // ... and a plain 256-term block, the fall-back when the folded block proves unselective
   if (h->cfg.head_terms > 0) {
-    k = std::min(h->cfg.head_terms <= 256 ? head_width(h->cfg.head_terms) : h->cfg.head_terms, kHeadMaxTerms);  // terms wanted
+    k = std::min(h->cfg.head_terms <= 256 ? head_width(h->cfg.head_terms, 0) : h->cfg.head_terms, kHeadMaxTerms);  // terms wanted
   } else if (n >= kHeadMinRows) {
     double best = 0.0, s2 = 0.0;
     size_t i = 0;
@@ -760,18 +770,22 @@ int32_t choose_head(apss_handle *h, bool *changed) {
     if (df[(size_t)order[i]] > 0) terms.push_back(order[i]);
   const int32_t old_k = h->head_k;
   const std::vector<int32_t> old_terms = h->head_terms;
+  const int32_t fold0 = (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) ? h->dbgcfg.fold_w : 256;
+  h->head_fold_w = fold0;
+  auto upload_columns = [&]() -> int32_t {
+    std::vector<int32_t> pos((size_t)dim, -1);
+    for (size_t i = 0; i < h->head_terms.size(); ++i) pos[(size_t)h->head_terms[i]] = head_column((int32_t)i, h->head_fold_w);
+    APSS_TRY(ensure(h, h->head_pos, (size_t)dim));
+    HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `pos` goes out of scope
+    return APSS_OK;
+  };
   for (;;) {
-    k = terms.empty() ? 0 : head_width((int32_t)terms.size());  // from here on: the width of a W row
+    k = terms.empty() ? 0 : head_width((int32_t)terms.size(), h->head_fold_w);  // from here on: the width of a W row
     const bool differs = k != old_k || terms != old_terms;
     h->head_k = k;
     h->head_terms = terms;
-    if (k && differs) {
-      std::vector<int32_t> pos((size_t)dim, -1);
-      for (size_t i = 0; i < terms.size(); ++i) pos[(size_t)terms[i]] = head_column((int32_t)i);
-      APSS_TRY(ensure(h, h->head_pos, (size_t)dim));
-      HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));  // `pos` goes out of scope
-    }
+    if (k && differs) APSS_TRY(upload_columns());
     if (!(k && differs && h->cfg.head_terms == 0)) break;  // (a block that is already in use has passed the test below)
     // the visit count says yes; now the other side of the ledger: every element the dense filter passes is reported,
     // de-duplicated and re-scored (measured: ~10 ns each).  At a low threshold on strongly skewed data that can be a
@@ -788,6 +802,23 @@ int32_t choose_head(apss_handle *h, bool *changed) {
     h->head_k = 0;
     h->head_terms.clear();
     break;
+  }
+  if (h->head_k > kHeadBlock && h->cfg.head_terms == 0 && !h->dbgcfg.fold_w && (h->head_k != old_k || h->head_terms != old_terms)) {
+    // a NARROWER folded block?  128 columns cost 0.76 of the second contraction's time and pass more chance pairs (a chance
+    // pair collides in m^2 / 128 columns instead of m^2 / 256): taken when the sampled survivors cost less than half the saving
+    h->head_fold_w = 128;
+    h->head_k = head_width((int32_t)h->head_terms.size(), 128);
+    APSS_TRY(upload_columns());
+    double frac = 0.0;
+    APSS_TRY(head_sample_selectivity(h, &frac));
+    // (what counts is what the narrower block passes IN EXCESS of the wider one: the sample's true pairs pass both)
+    if ((frac - h->head_sample_frac) * kHeadFoldSurvivorCost > 0.5 * kHeadFold128Gain) {
+      h->head_fold_w = 256;
+      h->head_k = head_width((int32_t)h->head_terms.size(), 256);
+      APSS_TRY(upload_columns());
+    } else {
+      h->head_sample_frac = frac;
+    }
   }
   *changed = h->head_k != old_k || h->head_terms != old_terms;
   return APSS_OK;
@@ -1001,8 +1032,9 @@ int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
 int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_base, const uint16_t *Wq, int64_t wq_rows,
                  float thr, int64_t n_cand) {
   const int kt = h->head_k;                        // width of a W row
-  const int kh = std::min(kt, kHeadBlock);        // width of one block = of one contraction
-  const int n_blocks = std::max(1, kt / kHeadBlock);
+  const int kh = std::min(kt, kHeadBlock);        // width of the first block
+  const int n_blocks = kt > kHeadBlock ? 2 : 1;
+  const int fold_w = kt - kHeadBlock;             // width of the folded block (128 | 256) when there is one
   if (nq <= 2 * kGemvQ) {
     HeadGemvArgs g{};
     g.Wq = Wq;
@@ -1025,7 +1057,8 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
     g.head_pairs = h->head_ctr.p + 1;
     const int64_t blocks = std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div(n_cand, 256 * (int64_t)h->head_parts)));
     for (int b = 0; b < n_blocks; ++b) {
-      g.blk = b;
+      g.chunk0 = b * (kHeadBlock / 8);
+      g.kh = b ? fold_w : kh;
       g.head_pairs = h->head_ctr.p + (b == 0 ? 1 : 3);  // (pairs sharing a term of the FIRST block: the statistic; the others' counts are dropped)
       hipLaunchKernelGGL(k_head_gemv, dim3((unsigned)blocks), dim3(256), 0, h->stream, g);
     }
@@ -1069,14 +1102,15 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
   const int64_t all_qblocks = g.n_qblocks, first_qblock0 = g.qblock0;
   const int64_t per_launch = std::max<int64_t>(1, (int64_t)(4e12 / ((double)kHeadQBlock * (double)ct * (double)my_ctiles)));
   for (int b = 0; b < n_blocks; ++b) {  // (block 1: the folded terms -- the same contraction, no pair statistic)
-    g.blk = b;
+    g.chunk0 = b * (kHeadBlock / 8);
     for (int64_t q0 = 0; q0 < all_qblocks; q0 += per_launch) {
       g.n_qblocks = (int32_t)std::min<int64_t>(per_launch, all_qblocks - q0);
       g.qblock0 = first_qblock0 + q0 * kHeadQBlock;
       const dim3 grid((unsigned)((int64_t)g.n_qblocks * g.n_panels));
       // (three tile buffers + the barrier in mid-tile pay at KH = 256 only: 0.69 vs 0.67 of the bf16 peak; narrow blocks are
       // bound by their epilogue and lose with it: profiles/r03_head_gemm.md)
-      if (b > 0) hipLaunchKernelGGL((k_head_gemm<256, false, 3>), grid, dim3(512), 0, h->stream, g);
+      if (b > 0 && fold_w == 128) hipLaunchKernelGGL((k_head_gemm<128, false, 2>), grid, dim3(512), 0, h->stream, g);
+      else if (b > 0) hipLaunchKernelGGL((k_head_gemm<256, false, 3>), grid, dim3(512), 0, h->stream, g);
       else if (kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, 2>), grid, dim3(512), 0, h->stream, g);
       else if (kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, 2>), grid, dim3(512), 0, h->stream, g);
       else hipLaunchKernelGGL((k_head_gemm<256, true, 3>), grid, dim3(512), 0, h->stream, g);
@@ -1119,6 +1153,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.head_pairs = h->st.head_survivors = 0;
   h->st.head_ms = h->st.head_flops = 0;
   h->st.head_terms = h->head_k ? (int64_t)h->head_terms.size() : 0;
+  h->st.head_columns = (uint32_t)h->head_k;
   if (n_results) *n_results = 0;
   APSS_TRY(ensure(h, h->counters, kCtrCount));
   h->st.filter_survivors = 0;
@@ -1421,9 +1456,13 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     if (dbg.tiles_per_launch > 0) tiles_per_launch = dbg.tiles_per_launch;
     tiles_per_launch = std::min<int64_t>(tiles_per_launch, std::max<int64_t>(1, 2000000000LL / std::max(1, a.n_chunks)));
   }
-  if (h->res_q.cap < (size_t)std::min<int64_t>(2 * nq, 1LL << 28)) {
-    // room for two hits per query up front: growing means running the whole probe again
-    const size_t cap0 = (size_t)std::max<int64_t>(1 << 20, std::min<int64_t>(2 * nq, 1LL << 28));
+  // room for two hits per query up front -- and, with a dense-head block, for what its filters passed on the policy's sample
+  // (a narrow folded block passes a few pairs per million: 1e8 of them at N = 1e7): growing means running the whole probe again
+  int64_t want_cap = std::min<int64_t>(2 * nq, 1LL << 28);
+  if (hybrid_wanted && h->head_sample_frac > 0.0)
+    want_cap = std::min<int64_t>(want_cap + (int64_t)(1.5 * h->head_sample_frac * (double)nq * (double)h->idx_rows), 1LL << 30);
+  if (h->res_q.cap < (size_t)want_cap) {
+    const size_t cap0 = (size_t)std::max<int64_t>(1 << 20, want_cap);
     APSS_TRY(ensure(h, h->res_q, cap0, 0, true));
     APSS_TRY(ensure(h, h->res_c, cap0, 0, true));
     APSS_TRY(ensure(h, h->res_s, cap0, 0, true));
@@ -1806,6 +1845,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   h->cx.cb = std::min(2 * h->cb, 32768);
   if (h->dbgcfg.cx_tile) h->cx.cb = h->dbgcfg.cx_tile;  // experiment hook (multiple of 64, <= 65536)
   h->no_acc8 = h->dbgcfg.no_acc8;
+  if (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) h->head_fold_w = h->dbgcfg.fold_w;
   h->cx.align = h->dbgcfg.seg_align == 16 ? 16 : kSegAlignC;
   h->cx.coarse = true;
   if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {
@@ -2063,17 +2103,18 @@ int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *term
     return fail(h, APSS_E_UNSUPPORTED, "a dense-head block needs the two-pass join (theta > 0, no EXACT_ACCUM / FORCE_* flag)");
   if (h->sharded && (h->cfg.flags & APSS_FLAG_ADMISSION))
     return fail(h, APSS_E_UNSUPPORTED, "a term shard packs the block's rows from the batch row by row: not with APSS_FLAG_ADMISSION");
+  h->head_fold_w = (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) ? h->dbgcfg.fold_w : 256;  // (no sample to justify fewer columns)
   std::vector<int32_t> pos((size_t)h->cfg.dim, -1);
   for (int32_t i = 0; i < n_terms; ++i) {
     if (terms[i] < 0 || terms[i] >= h->cfg.dim || pos[(size_t)terms[i]] >= 0)
       return fail(h, APSS_E_INVALID, "apss_set_head_terms: terms must be distinct and in [0, dim)");
-    pos[(size_t)terms[i]] = head_column(i);
+    pos[(size_t)terms[i]] = head_column(i, h->head_fold_w);
   }
   APSS_TRY(ensure(h, h->head_pos, (size_t)h->cfg.dim));
   HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)h->cfg.dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->head_terms.assign(terms, terms + n_terms);
-  h->head_k = head_width(n_terms);
+  h->head_k = head_width(n_terms, h->head_fold_w);
   h->head_fixed = true;
   h->head_blocked = false;
   h->head_part = part;

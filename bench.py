@@ -243,8 +243,8 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
                     "candidate_pairs_note": "max(pairs sharing a tail term, pairs sharing a head term): a lower bound of "
                                             "the distinct pairs scored (a pair sharing both kinds is scored by both filters)"})
         head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16)" % (
-                         min(256, st["head_terms"]), " x 2 blocks (256 terms with a column each + %d terms folded into 256 columns)"
-                         % (st["head_terms"] - 256) if st["head_terms"] > 256 else ""),
+                         min(256, st["head_terms"]), " + k_head_gemm<%d> (256 terms with a column each + %d terms folded into %d columns)"
+                         % (st["head_columns"] - 256, st["head_terms"] - 256, st["head_columns"] - 256) if st["head_terms"] > 256 else ""),
                      "achieved": flops / head_s / 1e12 if head_s > 0 else None, "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / head_s / 1e12 / MFMA_BF16_PEAK_TFLOPS if head_s > 0 else None,
                      "traffic": None,

@@ -101,7 +101,8 @@ typedef struct apss_stats {
                                shard's or a sparse batch's rounds of a few hundred postings) */
   uint32_t downgrades;      /* APSS_DOWNGRADE_*: permanent fallbacks (until apss_clear) this handle took because of a call it could
                                not serve on its fast layout; each costs one full index rebuild when it happens */
-  uint32_t reserved0;
+  uint32_t head_columns;    /* width of a row of the dense-head block at the last call: 64 | 128 | 256 for one block, 384 | 512 = 256 columns
+                               + a folded block of 128 | 256 (0: none) */
   char probe_kernel[96];    /* the probe kernel instantiation the last query-type call launched, as rocprofv3 prints its name up
                                to the template arguments' spelling, e.g. "k_probe_even<512,6,128,0,0,0>" (threads, window steps,
                                long-segment list, shard rule, signed, 8-bit accumulators); "" before any probe */

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm16(const HeadGemmArgs a) {
     const bool ok = row >= 0 && row < a.nq && s < a.wq_rows;
     wave_live |= ok;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq) + ((ok ? wslot0 : 0) / kHeadCTile) * (int64_t)(a.kt / 8 * kHeadCTile) +
-                       (int64_t)a.blk * (CPR * kHeadCTile) + 16 * m + r16;
+                       (int64_t)a.chunk0 * kHeadCTile + 16 * m + r16;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void k_head_gemm16(const HeadGemmArgs a) {
 
   auto copy_tile = [&](const int t, const int buf) {
     const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * ((int64_t)kHeadCTile * a.kt * 2) +
-                                (int64_t)a.blk * TILEB + ln * 16;
+                                (int64_t)a.chunk0 * (kHeadCTile * 16) + ln * 16;
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
       __builtin_amdgcn_global_load_lds(

@@ -86,7 +86,7 @@ int main(int argc, char **argv) {
   g.counters = ctr;
   g.head_pairs = ctr + 4;
   g.kt = kh;
-  g.blk = 0;
+  g.chunk0 = 0;
   g.part = 0;
   g.n_parts = 1;
   const bool m16 = getenv("M16") != nullptr;  // the v_mfma_f32_16x16x32_bf16 form of the kernel
