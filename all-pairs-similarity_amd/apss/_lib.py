@@ -15,7 +15,7 @@ SYMBOLS = [
     "apss_create", "apss_destroy", "apss_last_error", "apss_set_stream", "apss_insert", "apss_query",
     "apss_insert_and_query", "apss_self_join", "apss_result_count", "apss_fetch_results", "apss_size",
     "apss_stats_get", "apss_insert_dev", "apss_query_dev", "apss_insert_and_query_dev", "apss_clear",
-    "apss_results_dev", "apss_results_copy_dev", "apss_partial_scores_dev", "apss_set_head_terms", "apss_get_head_terms",
+    "apss_results_dev", "apss_results_copy_dev", "apss_partial_scores_dev", "apss_set_head_terms", "apss_get_head_terms", "apss_set_head_fold",
 ]
 DOWNGRADE_ACC8, DOWNGRADE_HEAD = 1, 2
 
@@ -135,6 +135,8 @@ def lib():
     L.apss_partial_scores_dev.argtypes = [vp, i64, vp, vp, vp]
     L.apss_set_head_terms.restype = i32
     L.apss_set_head_terms.argtypes = [vp, i32, vp, i32, i32]
+    L.apss_set_head_fold.restype = i32
+    L.apss_set_head_fold.argtypes = [vp, i32]
     L.apss_get_head_terms.restype = i32
     L.apss_get_head_terms.argtypes = [vp, i32, vp, C.POINTER(i32)]
     _lib = L

@@ -61,7 +61,8 @@ def hip_head_chooser(dim, theta, device, head_terms=0, sample_rows=131072):
         e = int(rp[m])
         with ApssIndex(dim, theta, device=device.index or 0, head_terms=head_terms) as ix:
             ix.insert(np.arange(m, dtype=np.int64), rp[:m + 1], idx[:e], val[:e])
-            return ix.head_terms()
+            cols = ix.stats()["head_columns"]
+            return ix.head_terms(), (cols - 256 if cols > 256 else 0)  # the terms and the folded block's columns it justified
     return choose
 
 
@@ -88,7 +89,7 @@ class HipShardEngine:
         self.device = device
         self.ix = ApssIndex(dim, theta, device=device.index or 0, tile_rows=tile_rows, term_range=term_range)
         if head is not None and len(head[0]):
-            self.ix.set_head_terms(head[0], head[1], head[2])
+            self.ix.set_head_terms(head[0], head[1], head[2], head[3] if len(head) > 3 else 0)
         # run on torch's stream: the tensors handed to the library are produced by torch kernels on that stream
         self.ix.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
@@ -200,20 +201,24 @@ class ShardedJoin:
         self.head_mode = head_terms
         self.head_chooser = head_chooser or hip_head_chooser(dim, theta, device, max(0, head_terms))
         self.head = np.zeros(0, np.int32)
+        self.head_fold = 0
         self.last = {}
 
     def _decide_head(self, rp, idx, val):
         """rank 0 asks the policy, every rank gets the same terms (one broadcast at load time, not in the data path)"""
-        buf = torch.zeros(8193, dtype=torch.int32, device=self.comm)
+        buf = torch.zeros(8194, dtype=torch.int32, device=self.comm)
         if self.rank == 0:
-            t = np.asarray(self.head_chooser(rp, idx, val), dtype=np.int32)[:8192]
-            buf[0] = int(t.size)
+            chosen = self.head_chooser(rp, idx, val)
+            t, fold = chosen if isinstance(chosen, tuple) else (chosen, 0)  # (terms, columns of the folded block | 0)
+            t = np.asarray(t, dtype=np.int32)[:8192]
+            buf[0], buf[1] = int(t.size), int(fold)
             if t.size:
-                buf[1:1 + t.size] = torch.from_numpy(t).to(self.comm)
+                buf[2:2 + t.size] = torch.from_numpy(t).to(self.comm)
         if self.world > 1:
             dist.broadcast(buf, src=0)
         h = buf.cpu().numpy()
-        return h[1:1 + int(h[0])].astype(np.int32)
+        self.head_fold = int(h[1])
+        return h[2:2 + int(h[0])].astype(np.int32)
 
     def load(self, rp, idx, val):
         """every rank holds the same batch (same seed / same broadcast); each indexes only its terms x rows"""
@@ -231,7 +236,7 @@ class ShardedJoin:
         self.n = len(rp) - 1
         self.row_range = (self.n * self.dj // self.D, self.n * (self.dj + 1) // self.D)
         if self.head.size:
-            self.engine = self.engine_factory(self.term_range, head=(self.head, self.ti, self.T))
+            self.engine = self.engine_factory(self.term_range, head=(self.head, self.ti, self.T, self.head_fold))
         else:
             self.engine = self.engine_factory(self.term_range)
         self.engine.load(rp, idx, val, None if self.D == 1 else self.row_range)

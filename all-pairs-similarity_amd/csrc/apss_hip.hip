@@ -177,6 +177,7 @@ struct apss_handle {
   int32_t head_k = 0;                 // 0: no block
   bool head_fixed = false;            // the block's terms were set through apss_set_head_terms: no policy, kept across apss_clear
   int32_t head_fold_w = 256;          // columns of the folded block (128 | 256)
+  int32_t head_fold_user = 0;         // ... as named by the caller for the terms it sets (apss_set_head_fold; 0: 256)
   bool head_longseg = false;          // term shard with a block: its tail still has segments too long for the thin-round kernel (a
                                       // hint kept across apss_clear: the next first build goes straight to the layout that serves them)
   int32_t head_part = 0, head_parts = 1;  // this handle multiplies the candidate tiles t % head_parts == head_part of the block
@@ -1109,7 +1110,9 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
       const dim3 grid((unsigned)((int64_t)g.n_qblocks * g.n_panels));
       // (three tile buffers + the barrier in mid-tile pay at KH = 256 only: 0.69 vs 0.67 of the bf16 peak; narrow blocks are
       // bound by their epilogue and lose with it: profiles/r03_head_gemm.md)
-      if (b > 0 && fold_w == 128) hipLaunchKernelGGL((k_head_gemm<128, false, 2>), grid, dim3(512), 0, h->stream, g);
+      // (the folded block has no positive count in its epilogue: there the three-buffer pipeline pays at 128 columns too,
+      // 0.60 -> 0.68 of the peak at N = 1M)
+      if (b > 0 && fold_w == 128) hipLaunchKernelGGL((k_head_gemm<128, false, 3>), grid, dim3(512), 0, h->stream, g);
       else if (b > 0) hipLaunchKernelGGL((k_head_gemm<256, false, 3>), grid, dim3(512), 0, h->stream, g);
       else if (kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, 2>), grid, dim3(512), 0, h->stream, g);
       else if (kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, 2>), grid, dim3(512), 0, h->stream, g);
@@ -2014,6 +2017,8 @@ int32_t apss_stats_get(apss_handle *h, apss_stats *out) {
   h->st.tiles = h->use_coarse && h->ex_built_rows < h->idx_rows ? h->cx.n_tiles : ceil_div(h->idx_rows, h->ex.cb);
   h->st.hbm_bytes = (int64_t)h->bytes_reserved;
   h->st.downgrades = h->downgrades;
+  h->st.head_terms = h->head_k ? (int64_t)h->head_terms.size() : 0;  // (as they are now: a policy handle is asked after its insert)
+  h->st.head_columns = (uint32_t)h->head_k;
   *out = h->st;
   return APSS_OK;
 }
@@ -2103,7 +2108,8 @@ int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *term
     return fail(h, APSS_E_UNSUPPORTED, "a dense-head block needs the two-pass join (theta > 0, no EXACT_ACCUM / FORCE_* flag)");
   if (h->sharded && (h->cfg.flags & APSS_FLAG_ADMISSION))
     return fail(h, APSS_E_UNSUPPORTED, "a term shard packs the block's rows from the batch row by row: not with APSS_FLAG_ADMISSION");
-  h->head_fold_w = (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) ? h->dbgcfg.fold_w : 256;  // (no sample to justify fewer columns)
+  // (no sample here to justify fewer columns: 256 unless the caller says what ITS sample justified, apss_set_head_fold)
+  h->head_fold_w = (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) ? h->dbgcfg.fold_w : (h->head_fold_user ? h->head_fold_user : 256);
   std::vector<int32_t> pos((size_t)h->cfg.dim, -1);
   for (int32_t i = 0; i < n_terms; ++i) {
     if (terms[i] < 0 || terms[i] >= h->cfg.dim || pos[(size_t)terms[i]] >= 0)
@@ -2121,6 +2127,14 @@ int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *term
   h->head_parts = n_parts;
   h->cx.n_tiles = 0;
   h->ex_built_rows = 0;
+  return APSS_OK;
+}
+
+int32_t apss_set_head_fold(apss_handle *h, int32_t columns) {
+  APSS_TRY(enter(h));
+  if (columns != 0 && columns != 128 && columns != 256) return fail(h, APSS_E_INVALID, "apss_set_head_fold: 0 (default), 128 or 256 columns");
+  if (h->n_rows != 0) return fail(h, APSS_E_STATE, "apss_set_head_fold: on an empty handle (it takes effect at the next apss_set_head_terms)");
+  h->head_fold_user = columns;
   return APSS_OK;
 }
 

@@ -19,6 +19,9 @@ object NativeApss {
     * every shard, worker `part` of `nParts` multiplying its share of the candidate tiles (include/apss.h,
     * apss_set_head_terms); empty handle only.  Returns 0 or a negative status */
   @native def setHeadTerms(h: Long, terms: Array[Int], part: Int, nParts: Int): Int
+  /** columns (128 | 256, 0 = default) of the folded block of a head of more than 256 terms: what the handle that chose the
+    * terms justified on its sample (headColumns - 256); before setHeadTerms */
+  @native def setHeadFold(h: Long, columns: Int): Int
   /** the block's terms, chosen by the library or set by setHeadTerms (what one shard's policy decided is what its peers are given) */
   @native def headTerms(h: Long): Array[Int]
 }

@@ -123,6 +123,11 @@ JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_setHeadTerms(JNIEnv *env, jcla
   return rc;
 }
 
+JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_setHeadFold(JNIEnv *env, jclass cls, jlong h, jint columns) {
+  (void)env; (void)cls;
+  return apss_set_head_fold(H(h), columns);
+}
+
 JNIEXPORT jintArray JNICALL Java_cpslab_gpu_NativeApss_headTerms(JNIEnv *env, jclass cls, jlong h) {
   (void)cls;
   int32_t n = 0;

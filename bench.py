@@ -440,11 +440,11 @@ def main():
         if T > 1 and a.head_terms >= 0:  # what rank 0 of the sharded join decides and broadcasts (apss/dist.py)
             from apss.dist import hip_head_chooser
             from apss.dist import limit_head_depth
-            terms = hip_head_chooser(cfg["dim"], cfg["theta"], dev, a.head_terms)(rp, idx, val)
+            terms, fold = hip_head_chooser(cfg["dim"], cfg["theta"], dev, a.head_terms)(rp, idx, val)
             if a.head_terms == 0:
                 terms = limit_head_depth(terms, df, n, T)
             if terms.size:
-                head = (terms, ti, T)
+                head = (terms, ti, T, fold)
                 df[terms] = 0
         tr = term_ranges(df, T)[ti]
         eng = HipShardEngine(cfg["dim"], cfg["theta"], tr, dev, a.tile_rows, head)

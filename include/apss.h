@@ -197,6 +197,12 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
  * apss_clear); the setting survives apss_clear; n_terms == 0 removes it.  Shards: non-negative weights, no
  * APSS_FLAG_ADMISSION (APSS_E_UNSUPPORTED otherwise). */
 int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *terms, int32_t part, int32_t n_parts);
+/* Columns of the FOLDED block (128 | 256; 0 = the default, 256) of a head of more than 256 terms set through
+ * apss_set_head_terms: fewer columns make the second contraction cheaper and pass more chance pairs; the library's own
+ * policy decides it on a sample, a caller that names the terms passes on what that sample justified (apss_stats.head_columns
+ * of the handle that chose them, minus 256).  Shards of one join need not agree on it.  Before apss_set_head_terms, on an
+ * empty handle. */
+int32_t apss_set_head_fold(apss_handle *h, int32_t columns);
 /* the block's terms in block order (chosen by the library or set by the caller); *n_terms = how many there are */
 int32_t apss_get_head_terms(apss_handle *h, int32_t capacity, int32_t *out_terms, int32_t *n_terms);
 

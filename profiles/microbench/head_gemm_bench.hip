@@ -118,6 +118,8 @@ int main(int argc, char **argv) {
     else if (m16 && kh == 128) hipLaunchKernelGGL(k_head_gemm16<128>, grid, dim3(512), 0, 0, g);
     else if (m16 && getenv("NOCOUNT")) hipLaunchKernelGGL((k_head_gemm16<256, false>), grid, dim3(512), 0, 0, g);
     else if (m16) hipLaunchKernelGGL(k_head_gemm16<256>, grid, dim3(512), 0, 0, g);
+    else if (getenv("NOCOUNT") && kh == 128 && getenv("PIPE3")) hipLaunchKernelGGL((k_head_gemm<128, false, 3>), grid, dim3(512), 0, 0, g);
+    else if (getenv("NOCOUNT") && kh == 128) hipLaunchKernelGGL((k_head_gemm<128, false, 2>), grid, dim3(512), 0, 0, g);
     else if (getenv("PIPE4")) hipLaunchKernelGGL((k_head_gemm<256, true, 4>), grid, dim3(512), 0, 0, g);
     else if (getenv("PIPE2") && kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, 2>), grid, dim3(512), 0, 0, g);
     else if (getenv("PIPE2") && kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, 2>), grid, dim3(512), 0, 0, g);

@@ -36,7 +36,7 @@ def _worker(rank, world, port, out_dir, term_shards, head_k=0):
     sj.load(rp, idx, val)
     assert sj.head.size == (head_k if term_shards > 1 else 0)
     if head_k and term_shards > 1:  # the block's terms are in no shard's tail test, and every rank holds the same block
-        assert sj.engine.head[1:] == (rank % term_shards, term_shards)
+        assert sj.engine.head[1:3] == (rank % term_shards, term_shards)
         assert float(abs(sj.engine.xt[:, [t - sj.term_range[0] for t in sj.head if sj.term_range[0] <= t < sj.term_range[1]]]).sum()) == 0.0
     q, c, s = sj.step(return_pairs=True)
     total = sj.step()

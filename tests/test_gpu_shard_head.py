@@ -20,7 +20,7 @@ def _top_terms(idx, dim, k):
     return np.lexsort((np.arange(dim), -df))[:k].astype(np.int32), df
 
 
-def _shard_engines(dim, theta, idx, T, head, row_range=None, rp=None, val=None, tile_rows=0):
+def _shard_engines(dim, theta, idx, T, head, row_range=None, rp=None, val=None, tile_rows=0, fold=0):
     import torch
     from apss.dist import HipShardEngine, term_ranges
     df = np.bincount(idx, minlength=dim)
@@ -28,7 +28,7 @@ def _shard_engines(dim, theta, idx, T, head, row_range=None, rp=None, val=None, 
         df = df.copy()
         df[head] = 0
     dev = torch.device("cuda", 0)
-    engines = [HipShardEngine(dim, theta, tr, dev, tile_rows=tile_rows, head=None if head is None else (head, i, T))
+    engines = [HipShardEngine(dim, theta, tr, dev, tile_rows=tile_rows, head=None if head is None else (head, i, T, fold))
                for i, tr in enumerate(term_ranges(df, T))]
     for e in engines:
         e.load(rp, idx, val, row_range)
@@ -45,9 +45,12 @@ def test_term_shards_with_a_head_block_match_oracle(oracle, T, kh, n, dim, nnz, 
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
     assert len(want) > 100
     head, df = _top_terms(idx, dim, kh)
-    engines = _shard_engines(dim, theta, idx, T, head, rp=rp, val=val, tile_rows=1024)
+    fold = 128 if (kh > 256 and T % 2 == 1) else 0  # (one case with the narrow folded block named by the caller)
+    engines = _shard_engines(dim, theta, idx, T, head, rp=rp, val=val, tile_rows=1024, fold=fold)
     q, c, s, n_cand = join_shards_local(engines, n, theta)
     assert_same_pairs(to_map(q, c, s), want, theta)
+    if kh > 256:
+        assert all(e.stats["head_columns"] == 256 + (fold or 256) for e in engines)
     tail_df = df.astype(np.int64).copy()
     tail_df[head] = 0
     # the block's terms are in no shard's index; every other posting is visited by exactly one shard
@@ -91,11 +94,14 @@ def test_c5_power_law_reduced_four_shards_policy_block(oracle):
     from apss.engine import ApssIndex
     cfg, rp, idx, val = synth.make_config("c5z", n=40_000, device="cuda")
     dim, theta, n = cfg["dim"], cfg["theta"], cfg["n"]
-    head = hip_head_chooser(dim, theta, torch.device("cuda", 0))(rp, idx, val)
+    head, fold = hip_head_chooser(dim, theta, torch.device("cuda", 0))(rp, idx, val)
     assert head.size in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and len(set(head.tolist())) == head.size
-    engines = _shard_engines(dim, theta, idx, 4, head, rp=rp, val=val)
+    assert fold in (0, 128, 256) and (fold > 0) == (head.size > 256)
+    engines = _shard_engines(dim, theta, idx, 4, head, rp=rp, val=val, fold=fold)
     q, c, s, n_cand = join_shards_local(engines, n, theta)
     got = to_map(q, c, s)
+    for e in engines:  # the folded block's width travelled with the terms
+        assert e.stats["head_columns"] == (256 + fold if head.size > 256 else e.stats["head_columns"])
     with ApssIndex(dim, theta, head_terms=-1) as ix:
         ref = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
     assert len(ref) > 1000
@@ -193,6 +199,9 @@ def test_set_head_terms_contract():
             assert e.value.code == _lib.E_INVALID
         with pytest.raises(ApssError) as e:
             ix.set_head_terms(head, 2, 2)
+        assert e.value.code == _lib.E_INVALID
+        with pytest.raises(ApssError) as e:
+            ix.set_head_terms(head, fold_columns=64)
         assert e.value.code == _lib.E_INVALID
         ix.set_head_terms(head)  # cfg.head_terms = -1 forbids the POLICY, not the caller
         for _ in range(2):

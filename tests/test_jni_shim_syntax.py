@@ -20,6 +20,6 @@ def test_jni_names_match_the_scala_declarations():
     scala = open(os.path.join(JVM, "NativeApss.scala")).read()
     natives = set(re.findall(r"@native def (\w+)", scala))
     exported = set(re.findall(r"Java_cpslab_gpu_NativeApss_(\w+)\(", c))
-    assert natives == exported and natives == {"create", "destroy", "lastError", "submit", "fetch", "setHeadTerms", "headTerms"}
+    assert natives == exported and natives == {"create", "destroy", "lastError", "submit", "fetch", "setHeadTerms", "setHeadFold", "headTerms"}
     # no critical sections: the library calls block on the GPU
     assert "GetPrimitiveArrayCritical(" not in c.split("*/", 1)[1]
