@@ -138,8 +138,9 @@ struct apss_handle {
     DevBuf<Posting> post;
     DevBuf<uint32_t> post_c;
     DevBuf<int64_t> base, total;
-    DevBuf<uint32_t> maxlen;   // [1] longest (tile, term) segment over the builds since the rendering was last started from tile 0
-    uint32_t max_seg = 0;      // its host copy
+    DevBuf<uint32_t> maxlen;   // [2] longest (tile, term) segment, number of long segments, over the builds since the rendering was last started from tile 0
+    uint32_t max_seg = 0;      // host copies
+    uint32_t long_segs = 0;
     std::vector<int64_t> h_base;
     double build_ms = 0;
   };
@@ -446,8 +447,8 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   APSS_TRY(ensure(h, ix.seg, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
   APSS_TRY(ensure(h, ix.base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
   APSS_TRY(ensure(h, ix.total, (size_t)n_tiles, 0));
-  APSS_TRY(ensure(h, ix.maxlen, 1));
-  if (tile0 == 0) HIPCHK(h, hipMemsetAsync(ix.maxlen.p, 0, sizeof(uint32_t), h->stream));
+  APSS_TRY(ensure(h, ix.maxlen, 2));
+  if (tile0 == 0) HIPCHK(h, hipMemsetAsync(ix.maxlen.p, 0, 2 * sizeof(uint32_t), h->stream));
   DevBuf<float> &tmin = ix.coarse ? h->tile_min_c : h->tile_min;
   const bool scaled = h->sharded || h->head_k > 0;  // the probe scales its threshold per query and tile (shard rule)
   if (scaled) APSS_TRY(ensure(h, tmin, (size_t)n_tiles, (size_t)tile0));
@@ -491,8 +492,11 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   // padded posting counts -> tile bases (host prefix sum: a handful of values), then reserve the posting array
   std::vector<int64_t> tot((size_t)(n_tiles - tile0));
   HIPCHK(h, hipMemcpyAsync(tot.data(), ix.total.p + tile0, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(&ix.max_seg, ix.maxlen.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  uint32_t seg_stats[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(seg_stats, ix.maxlen.p, sizeof(seg_stats), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  ix.max_seg = seg_stats[0];
+  ix.long_segs = seg_stats[1];
   for (size_t i = 0; i < tot.size(); ++i) ix.h_base.push_back(ix.h_base.back() + tot[i]);
   HIPCHK(h, hipMemcpyAsync(ix.base.p + tile0, ix.h_base.data() + tile0, (size_t)(n_tiles - tile0 + 1) * sizeof(int64_t),
                            hipMemcpyHostToDevice, h->stream));
@@ -1375,7 +1379,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     // LDS-throughput-bound): 100.6 vs 111.3 with six adding waves x 6 steps, 115.4 with 7 steps -- a plain 512-thread handle
     // takes it when its adding waves issue no more window steps per round than k_probe_coarse's eight would.
     const bool wide_ok = shard_rule || cxv.block == 1024 || dbg.even_wide;
-    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4) {
+    // (not where long segments abound -- more than 16 long terms per tile: the thin-round kernel sweeps them on its rare
+    // path, meant for one round in a few.  C3 with Zipf(0.5) terms, ~400 long terms per tile and half a dozen in every round,
+    // measured 1395 ms there against 518 ms on k_probe_coarse)
+    const bool few_longs = (double)h->cx.long_segs <= 16.0 * (double)std::max<int64_t>(1, h->cx.n_tiles) || shard_rule || cxv.block == 1024;
+    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4 && few_longs) {
       CxVariant ev = cxv;
       ev.even = true;
       const double add_waves = nw - (double)flat_waves;               // a wave that stages a round adds nothing in it

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
   __shared__ uint32_t wave_tot[17];
   uint2 *sg = tile_seg + (tile0 + blockIdx.x) * seg_stride;
   const int tid = threadIdx.x;
-  uint32_t carry = 0, longest = 0;
+  uint32_t carry = 0, longest = 0, n_long = 0;
   for (int32_t base = 0; base < dim; base += kScanBlock) {
     const int32_t i0 = base + tid * 4;
     uint32_t len[4], s = 0;
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
       len[k] = i0 + k < dim ? sg[i0 + k].y : 0u;
       s += (len[k] + align - 1) / align * align;
       longest = max(longest, len[k]);
+      n_long += len[k] > 256u ? 1u : 0u;  // (kLongLenW: what the probe kernels sweep as a long segment)
     }
     uint32_t total;
     uint32_t run = carry + block_excl_scan_1024<uint32_t>(s, wave_tot, &total);
@@ -393,8 +394,14 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
   }
   if (tid == 0) tile_total[tile0 + blockIdx.x] = carry;
   // the longest (tile, term) segment of the build: tells the probe whether its long-segment machinery is needed at all
-  for (int o = kWave / 2; o; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
-  if (max_len && (tid % kWave) == 0 && longest) atomicMax(max_len, longest);
+  for (int o = kWave / 2; o; o >>= 1) {
+    longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+    n_long += (uint32_t)__shfl_xor((int)n_long, o);
+  }
+  if (max_len && (tid % kWave) == 0 && longest) {
+    atomicMax(max_len, longest);
+    if (n_long) atomicAdd(max_len + 1, n_long);  // [1]: long segments over all tiles of the build
+  }
 }
 
 __global__ void k_tile_scatter(BuildArgs a) {
