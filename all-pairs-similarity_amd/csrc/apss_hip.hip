@@ -141,6 +141,8 @@ struct apss_handle {
     DevBuf<uint32_t> maxlen;   // [2] longest (tile, term) segment, number of long segments, over the builds since the rendering was last started from tile 0
     uint32_t max_seg = 0;      // host copies
     uint32_t long_segs = 0;
+    DevBuf<unsigned long long> chunkw;  // [1] sum over (tile, term) of length x chunks (k_tile_scan)
+    double round_chunks = 0.0;          // chunks an average stored row deals out per round (tile): chunkw / rows
     std::vector<int64_t> h_base;
     double build_ms = 0;
   };
@@ -448,7 +450,11 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   APSS_TRY(ensure(h, ix.base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
   APSS_TRY(ensure(h, ix.total, (size_t)n_tiles, 0));
   APSS_TRY(ensure(h, ix.maxlen, 2));
-  if (tile0 == 0) HIPCHK(h, hipMemsetAsync(ix.maxlen.p, 0, 2 * sizeof(uint32_t), h->stream));
+  APSS_TRY(ensure(h, ix.chunkw, 1));
+  if (tile0 == 0) {
+    HIPCHK(h, hipMemsetAsync(ix.maxlen.p, 0, 2 * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(ix.chunkw.p, 0, sizeof(unsigned long long), h->stream));
+  }
   DevBuf<float> &tmin = ix.coarse ? h->tile_min_c : h->tile_min;
   const bool scaled = h->sharded || h->head_k > 0;  // the probe scales its threshold per query and tile (shard rule)
   if (scaled) APSS_TRY(ensure(h, tmin, (size_t)n_tiles, (size_t)tile0));
@@ -487,16 +493,20 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   if (lds_build) hipLaunchKernelGGL(k_tile_hist_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
   else hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
   hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, ix.seg.p, stride, h->cfg.dim,
-                     tile0, ix.total.p, (uint32_t)ix.align, lds_build ? 1u : 0u, ix.maxlen.p);
+                     tile0, ix.total.p, (uint32_t)ix.align, lds_build ? 1u : 0u, ix.maxlen.p, tile0 == 0 ? ix.chunkw.p : nullptr);
   HIPCHK(h, hipGetLastError());
   // padded posting counts -> tile bases (host prefix sum: a handful of values), then reserve the posting array
   std::vector<int64_t> tot((size_t)(n_tiles - tile0));
   HIPCHK(h, hipMemcpyAsync(tot.data(), ix.total.p + tile0, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   uint32_t seg_stats[2] = {0, 0};
+  unsigned long long chunk_w = 0;
   HIPCHK(h, hipMemcpyAsync(seg_stats, ix.maxlen.p, sizeof(seg_stats), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&chunk_w, ix.chunkw.p, sizeof(chunk_w), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   ix.max_seg = seg_stats[0];
   ix.long_segs = seg_stats[1];
+  // (measured on a build from the first tile; an appended batch keeps the figure of the build before it)
+  if (tile0 == 0 && h->idx_rows > 0) ix.round_chunks = (double)chunk_w / (double)h->idx_rows;
   for (size_t i = 0; i < tot.size(); ++i) ix.h_base.push_back(ix.h_base.back() + tot[i]);
   HIPCHK(h, hipMemcpyAsync(ix.base.p + tile0, ix.h_base.data() + tile0, (size_t)(n_tiles - tile0 + 1) * sizeof(int64_t),
                            hipMemcpyHostToDevice, h->stream));
@@ -1393,6 +1403,14 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       // (mean + 2 sigma of a binomial share of the terms: the rounds beyond read their last chunks from the strip and end
       // with a whole-tile clear, ~2 % of them; at 3 sigma the T = 8 shard took a 3-step window: 24.8 vs 23.2 ms)
       double round_chunks = q_terms * cpt + 2.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
+      // ... that is the uniform-terms estimate; the index build MEASURED what an average stored row deals out per tile
+      // (sum over terms of P(term in the row) x chunks of its segment): under a skewed distribution the terms a query holds
+      // are the ones with the long segments, and the estimate above falls short by a factor (power-law C5's tail: 85
+      // estimated, 200 dealt out: most rounds overflowed their window, a whole-tile clear each)
+      if (ix.round_chunks > 0.0) {
+        const double per_term = std::max(1.0, ix.round_chunks / std::max(1.0, q_terms));
+        round_chunks = std::max(round_chunks, ix.round_chunks + 2.0 * std::sqrt(ix.round_chunks * per_term));
+      }
       // (a plain handle's rows are whole rows: no binomial share of the terms; the longest row bounds the round)
       if (!shard_rule) round_chunks = std::min(round_chunks, 1.05 * (double)s_max_nnz * cpt);
       int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
@@ -1914,7 +1932,7 @@ void apss_destroy(apss_handle *h) {
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   release(h->rowptr); release(h->ext); release(h->idx); release(h->erow); release(h->val); release(h->sub);
-  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); release(s->maxlen); }
+  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); release(s->maxlen); release(s->chunkw); }
   release(h->tile_min); release(h->tile_min_c); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst); release(h->scan_tmp);

@@ -364,13 +364,15 @@ __global__ void k_tile_hist(BuildArgs a) {
 
 // one workgroup per tile: exclusive scan of the aligned lengths; tile_total[tile] = postings incl. padding
 __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0,
-                                                    int64_t *tile_total, uint32_t align, uint32_t keep_len, uint32_t *max_len) {
+                                                    int64_t *tile_total, uint32_t align, uint32_t keep_len, uint32_t *max_len,
+                                                    unsigned long long *chunk_w) {
   // one workgroup per tile walks the tile's dim entries in blocks of kScanBlock, four CONSECUTIVE entries per thread (a
   // strided stream per thread took 4.2 ms per build at dim = 2^20, 16 tiles)
   __shared__ uint32_t wave_tot[17];
   uint2 *sg = tile_seg + (tile0 + blockIdx.x) * seg_stride;
   const int tid = threadIdx.x;
   uint32_t carry = 0, longest = 0, n_long = 0;
+  unsigned long long cw = 0;  // sum over the tile's short segments of length x 16-posting chunks
   for (int32_t base = 0; base < dim; base += kScanBlock) {
     const int32_t i0 = base + tid * 4;
     uint32_t len[4], s = 0;
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
       s += (len[k] + align - 1) / align * align;
       longest = max(longest, len[k]);
       n_long += len[k] > 256u ? 1u : 0u;  // (kLongLenW: what the probe kernels sweep as a long segment)
+      cw += len[k] <= 256u ? (unsigned long long)len[k] * ((len[k] + 15u) / 16u) : 0ull;
     }
     uint32_t total;
     uint32_t run = carry + block_excl_scan_1024<uint32_t>(s, wave_tot, &total);
@@ -402,6 +405,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
     atomicMax(max_len, longest);
     if (n_long) atomicAdd(max_len + 1, n_long);  // [1]: long segments over all tiles of the build
   }
+  // A row of the tile holds term t with probability len_t / rows, and a query holding t meets ceil(len_t / 16) chunks of this
+  // tile: sum_t len_t * ceil(len_t / 16) / rows = the chunks an average round (a query distributed like the tile's rows) deals
+  // out, whatever the term distribution -- what the probe sizes its register window from
+  for (int o = kWave / 2; o; o >>= 1) cw += __shfl_xor(cw, o);
+  if (chunk_w && (tid % kWave) == 0 && cw) atomicAdd(chunk_w, cw);
 }
 
 __global__ void k_tile_scatter(BuildArgs a) {
