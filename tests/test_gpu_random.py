@@ -61,7 +61,7 @@ def test_random_streams(oracle, seed, monkeypatch):
         assert ix.size()[0] == len(ids)
 
 
-@pytest.mark.parametrize("head", [-1, 64])
+@pytest.mark.parametrize("head", [-1, 64, 600])
 def test_single_vector_messages_wait_in_the_tail(oracle, head):
     """the LoadGenerator shape (benchmark/LoadGenerator.scala:58-74): after a warm-up batch, thousands of single-vector
     IndexData messages.  They wait in the tail (scored pair by pair, k_tail_score) and are folded into the tile index
@@ -88,7 +88,8 @@ def test_single_vector_messages_wait_in_the_tail(oracle, head):
             r += sz
         assert found > 1000 and ix.size()[0] == r
         st = ix.stats()
-        assert st["head_terms"] == (64 if head > 0 else 0)
+        assert st["head_terms"] == (head if head > 0 else 0)  # (600: 256 columns + a folded block; the waiting rows' own W rows
+        # and tail views are made when they are folded into the index)
         # frozen-index query while rows wait in the tail
         sl = slice(rp[100], rp[140])
         got = to_map(*ix.query(np.arange(100, 140), rp[100:141] - rp[100], idx[sl], val[sl]))
@@ -98,17 +99,19 @@ def test_single_vector_messages_wait_in_the_tail(oracle, head):
         assert_same_pairs(to_map(*ix.self_join()), full, theta)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(24))
 def test_random_streams_with_a_forced_head_block(oracle, seed, monkeypatch):
     """the same randomised streams (ragged rows: empty, single-term, long; duplicate ids; several batches; thresholds from
     0.05 to 0.9) with the dense-head block forced on: rows without a head entry, rows with nothing BUT head entries (tail
     ratio 0), dims smaller than the block (the block is refused), batches that wait in the tail, the no_tail hook"""
     from apss.engine import ApssIndex
     if seed % 4 == 3:
-        monkeypatch.setenv("APSS_DEBUG", "no_tail")
+        monkeypatch.setenv("APSS_DEBUG", "no_tail" + (",fold_w=128" if seed % 8 == 7 else ""))
+    elif seed % 4 == 2:
+        monkeypatch.setenv("APSS_DEBUG", "fold_w=128")
     rng = np.random.default_rng(5000 + seed)
     dim, theta, ids, rp, idx, val, cuts = _random_case(rng)
-    kh = [64, 128, 256][seed % 3]
+    kh = [64, 128, 256, 400, 1500][seed % 5]  # (beyond 256: a folded second block; dims below the width: every term in the head)
     w = oracle.Worker(dim, theta)
     with ApssIndex(dim, theta, tile_rows=int(rng.choice([64, 1024, 0])), head_terms=kh) as ix:
         for b0, b1 in zip(cuts[:-1], cuts[1:]):
