@@ -278,3 +278,61 @@ def test_c1_every_document_plain_and_through_term_shards():
     assert_same_pairs(to_map(q, c, s), want, theta)
     for e in engines:
         assert e.stats["filter_survivors"] > 0 and e.stats["probe_kernel"].startswith(("k_probe_coarse<", "k_probe_even<")), e.stats
+
+
+@pytest.mark.parametrize("kh", [64, 900])
+def test_streaming_batches_on_term_shards_with_a_head_block(oracle, kh):
+    """the IndexData handler batch after batch (IndexingWorkerActor.scala:123-137) on three term shards that share a head
+    block: W rows, ratios and tail views are APPENDED per batch (batches that end inside a 64-row tile and inside an 8-row
+    pack group); after the stream a frozen-index query batch (outside rows: packed on the fly).  Exchange by hand, as
+    apss.dist does it; every batch's answer equals the oracle worker's"""
+    import torch
+    from apss.dist import term_ranges
+    from apss.engine import ApssIndex
+    n, dim, nnz, theta = 5000, 2500, 20, 0.5
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=123 + kh, dup_frac=0.15)
+    head, df = _top_terms(idx, dim, kh)
+    dft = df.copy()
+    dft[head] = 0
+    dev = torch.device("cuda", 0)
+    shards = []
+    for i, tr in enumerate(term_ranges(dft, 3)):
+        ix = ApssIndex(dim, theta, term_range=tr)
+        ix.set_head_terms(head, i, 3)
+        shards.append(ix)
+    w = oracle.Worker(dim, theta)
+
+    def joined(call, ids, b0, b1, n_store):
+        sl = slice(rp[b0], rp[b1])
+        args = (ids, rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl])
+        keys = []
+        for ix in shards:
+            qq, cc, _ = getattr(ix, call)(*args)  # external ids: batch rows are b0.., stored rows 0..
+            keys.append((qq - b0) * n + cc)
+        uniq = np.unique(np.concatenate(keys)) if keys else np.zeros(0, np.int64)
+        uq = torch.from_numpy(uniq // n).to(dev).to(torch.int32)
+        uc = torch.from_numpy(uniq % n).to(dev).to(torch.int32)
+        total = torch.zeros(uniq.size, dtype=torch.float32, device=dev)
+        for ix in shards:
+            part = torch.empty_like(total)
+            if uniq.size:
+                ix.partial_scores_dev(uq, uc, part)
+                total += part
+        keep = (total >= theta).cpu().numpy()
+        return {(int(a) + b0, int(b)): float(x) for a, b, x in zip(uniq[keep] // n, uniq[keep] % n, total.cpu().numpy()[keep])}
+
+    cuts = [0, 1003, 1900, 1967, 4100]
+    for b0, b1 in zip(cuts[:-1], cuts[1:]):
+        sl = slice(rp[b0], rp[b1])
+        want = to_map(*w.index_data(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl]))
+        got = joined("insert_and_query", np.arange(b0, b1), b0, b1, b1)
+        assert_same_pairs(got, want, theta, band=2e-5, tol=2e-5)
+    b0, b1 = 4100, 5000  # never stored: an outside batch against the frozen index
+    sl = slice(rp[b0], rp[b1])
+    want = to_map(*w.index_data(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl], query_only=True))
+    got = joined("query", np.arange(b0, b1), b0, b1, 4100)
+    assert len(want) > 50
+    assert_same_pairs(got, want, theta, band=2e-5, tol=2e-5)
+    for ix in shards:
+        assert ix.stats()["head_terms"] == kh and ix.size()[0] == 4100
+        ix.close()
