@@ -1490,6 +1490,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   int64_t want_cap = std::min<int64_t>(2 * nq, 1LL << 28);
   if (hybrid_wanted && h->head_sample_frac > 0.0)
     want_cap = std::min<int64_t>(want_cap + (int64_t)(1.5 * h->head_sample_frac * (double)nq * (double)h->idx_rows), 1LL << 30);
+  else if (hybrid_wanted && h->sharded)  // (a shard was given its head: no sample of its own; power-law C5 measured ~1 per query and shard)
+    want_cap = std::min<int64_t>(want_cap + 6 * nq, 1LL << 30);
   if (h->res_q.cap < (size_t)want_cap) {
     const size_t cap0 = (size_t)std::max<int64_t>(1 << 20, want_cap);
     APSS_TRY(ensure(h, h->res_q, cap0, 0, true));
