@@ -61,8 +61,7 @@ def hip_head_chooser(dim, theta, device, head_terms=0, sample_rows=131072):
         e = int(rp[m])
         with ApssIndex(dim, theta, device=device.index or 0, head_terms=head_terms) as ix:
             ix.insert(np.arange(m, dtype=np.int64), rp[:m + 1], idx[:e], val[:e])
-            cols = ix.stats()["head_columns"]
-            return ix.head_terms(), (cols - 256 if cols > 256 else 0)  # the terms and the folded block's columns it justified
+            return ix.head_terms(), 0  # the terms; 0 = the library's default split of a wide head's 256 columns
     return choose
 
 

@@ -127,8 +127,8 @@ class ApssIndex:
 
     def set_head_terms(self, terms, part=0, n_parts=1, fold_columns=0):
         """dense-head block named by the caller (every term shard of a join gets the same terms; shard `part` of `n_parts`
-        multiplies its share of the candidate tiles); fold_columns: 128 | 256 columns of the folded block (0: default); empty
-        handle only"""
+        multiplies its share of the candidate tiles); fold_columns: how many of a wide head's 256 columns are folded ones
+        (64 | 128 | 192; 0: the default, 128); empty handle only"""
         t = _np(terms, np.int32)
         self._chk(self._L.apss_set_head_fold(self._h, int(fold_columns)))
         self._chk(self._L.apss_set_head_terms(self._h, t.size, _ptr(t), int(part), int(n_parts)))

@@ -102,6 +102,7 @@ struct HeadPackArgs {
   const float *row_inv;    // [rows of the CSR] or null: factor of every value (APSS_FLAG_NORMALIZE, k_ingest_count)
   float prune_above;       // an entry counts iff value * row_inv > prune_above (APSS_FLAG_VALUE_PRUNE; -inf: every entry)
   int32_t part, n_parts;   // head_nonempty counts the rows of the W tiles t % n_parts == part only (n_parts <= 1: every row)
+  int32_t fold_from;       // columns >= fold_from are FOLDED (several terms add into them); below: one term per column
 };
 
 // one wave per W row, 8 rows (one 128-B line per chunk) per workgroup; the workgroup covers W rows [8 g, 8 g + 8)
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
       if (hp >= 0 && v > a.prune_above) {
         // (block 0: a column belongs to one term, a plain store; block 1: the terms of a column ADD -- |x_{H_2}| above is the
         // norm of the entries themselves, not of the folded row)
-        if (hp < kHeadBlock) rowbuf[wv][hp] = v * scale[0];
-        else atomicAdd(&rowbuf[wv][hp], v * scale[1]);
+        if (hp < a.fold_from) rowbuf[wv][hp] = v * scale[0];
+        else atomicAdd(&rowbuf[wv][hp], v * (hp < kHeadBlock ? scale[0] : scale[1]));
       }
     }
     if (lane == 0) {

@@ -56,6 +56,7 @@ struct DebugCfg {
   int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
   bool bank_order = false;     // bank_order     experiment: bank-aware posting order inside short segments (k_seg_bank_order)
   int fold_w = 0;              // fold_w=N       columns of the dense head's folded block (128 | 256)
+  int mix = 0;                 // mix=E          ONE head block of 256 columns: E terms with a column each, the others folded into 256 - E
 };
 
 DebugCfg parse_debug_env() {
@@ -93,6 +94,7 @@ DebugCfg parse_debug_env() {
     else if (key == "seg_align") d.seg_align = val;
     else if (key == "bank_order") d.bank_order = val != 0;
     else if (key == "fold_w") d.fold_w = val;
+    else if (key == "mix") d.mix = val;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -179,8 +181,12 @@ struct apss_handle {
   // dense-head block (apss_head.hpp): the KH most frequent terms live in W instead of the inverted index
   int32_t head_k = 0;                 // 0: no block
   bool head_fixed = false;            // the block's terms were set through apss_set_head_terms: no policy, kept across apss_clear
-  int32_t head_fold_w = 256;          // columns of the folded block (128 | 256)
-  int32_t head_fold_user = 0;         // ... as named by the caller for the terms it sets (apss_set_head_fold; 0: 256)
+  // geometry of a head of more than 256 terms: ONE block of 256 columns -- the head_exact most frequent terms with a column
+  // each, the others FOLDED into the remaining head_fold_w = 256 - head_exact columns.  (APSS_DEBUG=fold_w=128|256 keeps
+  // round 3's first form for comparison: 256 columns with a term each + a second block of fold_w folded columns.)
+  int32_t head_fold_w = 128;
+  int32_t head_exact = 128;
+  int32_t head_fold_user = 0;         // folded columns named by the caller for the terms it sets (apss_set_head_fold; 0: 128)
   bool head_longseg = false;          // term shard with a block: its tail still has segments too long for the thin-round kernel (a
                                       // hint kept across apss_clear: the next first build goes straight to the layout that serves them)
   int32_t head_part = 0, head_parts = 1;  // this handle multiplies the candidate tiles t % head_parts == head_part of the block
@@ -420,6 +426,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
     p.head_nonempty = reinterpret_cast<unsigned int *>(h->head_ctr.p);
     p.row_inv = (h->cfg.flags & APSS_FLAG_NORMALIZE) ? h->s_inv.p : nullptr;
     p.prune_above = (h->cfg.flags & APSS_FLAG_VALUE_PRUNE) ? (float)h->cfg.index_threshold : -INFINITY;
+    p.fold_from = h->head_exact;
     p.part = h->head_part;  // (a stored query's product with itself is counted by the shard that owns its tile)
     p.n_parts = h->head_parts;
     hipLaunchKernelGGL(k_head_pack, dim3((unsigned)(ceil_div(w_pad, 8) - dst_row0 / 8)), dim3(512), 0, h->stream, p);
@@ -564,23 +571,17 @@ constexpr int64_t kTailMaxBatch = 256;   // a batch larger than this extends the
 constexpr int64_t kTailMaxPairs = 1 << 22;  // (queries x tail rows) a probe scores directly; beyond it the tail is folded in first
 constexpr int32_t kHeadMaxTerms = kHeadBlock * (1 + kHeadMaxFold);   // 256 terms with a column each + 256 columns of kHeadMaxFold terms
 // width of a W row holding n_terms head terms: one block of 64 | 128 | 256 columns, or 256 + a folded block of fold_w columns
-inline int32_t head_width(int32_t n_terms, int32_t fold_w) {
-  return n_terms <= 64 ? 64 : (n_terms <= 128 ? 128 : (n_terms <= 256 ? 256 : kHeadBlock + fold_w));
+inline int32_t head_width(int32_t n_terms, int32_t fold_w, int32_t exact = kHeadBlock) {
+  return n_terms <= 64 ? 64 : (n_terms <= 128 ? 128 : (n_terms <= 256 ? 256 : exact + fold_w));
 }
-// column of the i-th head term (most frequent first): the first 256 get a column each, the others fold into the second block
-inline int32_t head_column(int32_t i, int32_t fold_w) { return i < kHeadBlock ? i : kHeadBlock + (i - kHeadBlock) % fold_w; }
+// column of the i-th head term (most frequent first): the first `exact` get a column each, the others fold into fold_w columns
+inline int32_t head_column(int32_t i, int32_t fold_w, int32_t exact = kHeadBlock) { return i < exact ? i : exact + (i - exact) % fold_w; }
 constexpr int64_t kHeadMinRows = 16384;  // below this a join is over before a GEMM pays for its set-up
 constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse filter (measured, C3)
 // seconds per (query, candidate) element of the head contraction, block width 64 / 128 / 256 (measured on random rows,
 // profiles/r02_head_gemm.md: 1.65 PFLOP/s at 256; narrower blocks are bound by the epilogue's scan, not by the MFMAs)
-constexpr double kHeadDenseCost[4] = {1.5e-13, 1.9e-13, 3.1e-13, 6.2e-13};  // (last: two blocks of 256 = 256 terms + a folded block)
-// seconds per element a folded block of 128 columns saves over one of 256 (k_head_gemm<128> vs <256>; measured on power-law
-// C5 at N = 2M: 1259 -> 1024 ms per 2e12 elements of a stored batch)
-constexpr double kHeadFold128Gain = 1.2e-13;
-// ... and seconds per pair it passes in excess (measured: C3 with Zipf(1) terms, 5.6e6 more survivors, + 5 ms of reporting,
-// de-duplication and re-scoring; doubled)
-constexpr double kHeadFoldSurvivorCost = 2.0e-9;
-constexpr double kHeadFoldMaxRowTerms = 64.0;  // terms of the folded block a row may hold on average (chance pairs collide in m^2 / 256 columns)
+constexpr double kHeadDenseCost[4] = {1.5e-13, 1.9e-13, 3.1e-13, 3.1e-13};  // (last: a head of more than 256 terms -- still ONE block of 256 columns)
+constexpr double kHeadFoldMaxRowTerms = 96.0;  // terms of the folded block a row may hold on average (chance pairs collide in m^2 / 256 columns)
 constexpr double kHeadSurvivorCost = 1.0e-8;  // seconds per element the dense filter passes on (report + de-dup + exact re-score)
 
 // A plain handle decides for itself (choose_head) unless the block's terms were set through apss_set_head_terms; a term
@@ -667,6 +668,7 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
     a.head_nonempty = reinterpret_cast<unsigned int *>(h->head_ctr.p);
     a.row_inv = nullptr;
     a.prune_above = -INFINITY;  // (the store holds the rows as they are scored)
+    a.fold_from = h->head_exact;
     hipLaunchKernelGGL(k_head_pack, dim3((unsigned)(ceil_div(rows_pad, 8) - row0 / 8)), dim3(512), 0, h->stream, a);
   }
   HIPCHK(h, hipGetLastError());
@@ -711,6 +713,7 @@ int32_t head_sample_selectivity(apss_handle *h, double *frac) {
   p.head_nonempty = nullptr;
   p.row_inv = nullptr;
   p.prune_above = -INFINITY;
+  p.fold_from = h->head_exact;
   hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(p.w_pad, 8)), dim3(512), 0, h->stream, p);
   HIPCHK(h, hipGetLastError());
   ProbeArgs a{};
@@ -765,7 +768,7 @@ int32_t choose_head(apss_handle *h, bool *changed) {
       for (; i < std::min<size_t>(top, (size_t)kk); ++i) {
         const double f = (double)df[(size_t)order[i]] / (double)sampled;
         s2 += f * f;
-        if (i >= (size_t)kHeadBlock) m_fold += f;
+        if (i >= (size_t)h->head_exact) m_fold += f;
       }
       if (m_fold > kHeadFoldMaxRowTerms) break;
       // per N^2 pairs of a stored batch: df_t^2 = f_t^2 N^2 visits saved; half of the product computed (symmetric).  A head
@@ -785,18 +788,16 @@ int32_t choose_head(apss_handle *h, bool *changed) {
     if (df[(size_t)order[i]] > 0) terms.push_back(order[i]);
   const int32_t old_k = h->head_k;
   const std::vector<int32_t> old_terms = h->head_terms;
-  const int32_t fold0 = (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) ? h->dbgcfg.fold_w : 256;
-  h->head_fold_w = fold0;
   auto upload_columns = [&]() -> int32_t {
     std::vector<int32_t> pos((size_t)dim, -1);
-    for (size_t i = 0; i < h->head_terms.size(); ++i) pos[(size_t)h->head_terms[i]] = head_column((int32_t)i, h->head_fold_w);
+    for (size_t i = 0; i < h->head_terms.size(); ++i) pos[(size_t)h->head_terms[i]] = head_column((int32_t)i, h->head_fold_w, h->head_exact);
     APSS_TRY(ensure(h, h->head_pos, (size_t)dim));
     HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));  // `pos` goes out of scope
     return APSS_OK;
   };
   for (;;) {
-    k = terms.empty() ? 0 : head_width((int32_t)terms.size(), h->head_fold_w);  // from here on: the width of a W row
+    k = terms.empty() ? 0 : head_width((int32_t)terms.size(), h->head_fold_w, h->head_exact);  // from here on: the width of a W row
     const bool differs = k != old_k || terms != old_terms;
     h->head_k = k;
     h->head_terms = terms;
@@ -817,23 +818,6 @@ int32_t choose_head(apss_handle *h, bool *changed) {
     h->head_k = 0;
     h->head_terms.clear();
     break;
-  }
-  if (h->head_k > kHeadBlock && h->cfg.head_terms == 0 && !h->dbgcfg.fold_w && (h->head_k != old_k || h->head_terms != old_terms)) {
-    // a NARROWER folded block?  128 columns cost 0.76 of the second contraction's time and pass more chance pairs (a chance
-    // pair collides in m^2 / 128 columns instead of m^2 / 256): taken when the sampled survivors cost less than half the saving
-    h->head_fold_w = 128;
-    h->head_k = head_width((int32_t)h->head_terms.size(), 128);
-    APSS_TRY(upload_columns());
-    double frac = 0.0;
-    APSS_TRY(head_sample_selectivity(h, &frac));
-    // (what counts is what the narrower block passes IN EXCESS of the wider one: the sample's true pairs pass both)
-    if ((frac - h->head_sample_frac) * kHeadFoldSurvivorCost > 0.5 * kHeadFold128Gain) {
-      h->head_fold_w = 256;
-      h->head_k = head_width((int32_t)h->head_terms.size(), 256);
-      APSS_TRY(upload_columns());
-    } else {
-      h->head_sample_frac = frac;
-    }
   }
   *changed = h->head_k != old_k || h->head_terms != old_terms;
   return APSS_OK;
@@ -1821,6 +1805,7 @@ int32_t pack_query_head(apss_handle *h, const int64_t *rowptr, const int32_t *id
   a.head_nonempty = nullptr;
   a.row_inv = nullptr;
   a.prune_above = -INFINITY;
+  a.fold_from = h->head_exact;
   hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(q_pad, 8)), dim3(512), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   return APSS_OK;
@@ -1876,7 +1861,13 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   h->cx.cb = std::min(2 * h->cb, 32768);
   if (h->dbgcfg.cx_tile) h->cx.cb = h->dbgcfg.cx_tile;  // experiment hook (multiple of 64, <= 65536)
   h->no_acc8 = h->dbgcfg.no_acc8;
-  if (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) h->head_fold_w = h->dbgcfg.fold_w;
+  if (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) {  // experiment: two blocks
+    h->head_exact = 256;
+    h->head_fold_w = h->dbgcfg.fold_w;
+  } else if (h->dbgcfg.mix >= 32 && h->dbgcfg.mix <= 224 && h->dbgcfg.mix % 32 == 0) {  // experiment: another split of the one block
+    h->head_exact = h->dbgcfg.mix;
+    h->head_fold_w = 256 - h->dbgcfg.mix;
+  }
   h->cx.align = h->dbgcfg.seg_align == 16 ? 16 : kSegAlignC;
   h->cx.coarse = true;
   if (h->cb < 64 || h->cb > 32768 || (h->cb % 64)) {
@@ -2136,19 +2127,21 @@ int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *term
     return fail(h, APSS_E_UNSUPPORTED, "a dense-head block needs the two-pass join (theta > 0, no EXACT_ACCUM / FORCE_* flag)");
   if (h->sharded && (h->cfg.flags & APSS_FLAG_ADMISSION))
     return fail(h, APSS_E_UNSUPPORTED, "a term shard packs the block's rows from the batch row by row: not with APSS_FLAG_ADMISSION");
-  // (no sample here to justify fewer columns: 256 unless the caller says what ITS sample justified, apss_set_head_fold)
-  h->head_fold_w = (h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) ? h->dbgcfg.fold_w : (h->head_fold_user ? h->head_fold_user : 256);
+  if (!(h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256) && !h->dbgcfg.mix) {  // (the experiments' geometry stays)
+    h->head_fold_w = h->head_fold_user ? h->head_fold_user : 128;
+    h->head_exact = 256 - h->head_fold_w;
+  }
   std::vector<int32_t> pos((size_t)h->cfg.dim, -1);
   for (int32_t i = 0; i < n_terms; ++i) {
     if (terms[i] < 0 || terms[i] >= h->cfg.dim || pos[(size_t)terms[i]] >= 0)
       return fail(h, APSS_E_INVALID, "apss_set_head_terms: terms must be distinct and in [0, dim)");
-    pos[(size_t)terms[i]] = head_column(i, h->head_fold_w);
+    pos[(size_t)terms[i]] = head_column(i, h->head_fold_w, h->head_exact);
   }
   APSS_TRY(ensure(h, h->head_pos, (size_t)h->cfg.dim));
   HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)h->cfg.dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->head_terms.assign(terms, terms + n_terms);
-  h->head_k = head_width(n_terms, h->head_fold_w);
+  h->head_k = head_width(n_terms, h->head_fold_w, h->head_exact);
   h->head_fixed = true;
   h->head_blocked = false;
   h->head_part = part;
@@ -2160,7 +2153,7 @@ int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *term
 
 int32_t apss_set_head_fold(apss_handle *h, int32_t columns) {
   APSS_TRY(enter(h));
-  if (columns != 0 && columns != 128 && columns != 256) return fail(h, APSS_E_INVALID, "apss_set_head_fold: 0 (default), 128 or 256 columns");
+  if (columns != 0 && columns != 64 && columns != 128 && columns != 192) return fail(h, APSS_E_INVALID, "apss_set_head_fold: 0 (default: 128), 64, 128 or 192 columns");
   if (h->n_rows != 0) return fail(h, APSS_E_STATE, "apss_set_head_fold: on an empty handle (it takes effect at the next apss_set_head_terms)");
   h->head_fold_user = columns;
   return APSS_OK;

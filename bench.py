@@ -243,8 +243,8 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
                     "candidate_pairs_note": "max(pairs sharing a tail term, pairs sharing a head term): a lower bound of "
                                             "the distinct pairs scored (a pair sharing both kinds is scored by both filters)"})
         head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16)" % (
-                         min(256, st["head_terms"]), " + k_head_gemm<%d> (256 terms with a column each + %d terms folded into %d columns)"
-                         % (st["head_columns"] - 256, st["head_terms"] - 256, st["head_columns"] - 256) if st["head_terms"] > 256 else ""),
+                         min(256, st["head_columns"]), " (one block: 128 terms with a column each + %d terms folded into 128 columns)"
+                         % (st["head_terms"] - 128) if st["head_terms"] > 256 else ""),
                      "achieved": flops / head_s / 1e12 if head_s > 0 else None, "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / head_s / 1e12 / MFMA_BF16_PEAK_TFLOPS if head_s > 0 else None,
                      "traffic": None,
@@ -346,7 +346,7 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
             nt = sj.last["head_terms"]
             kh = 64 if nt <= 64 else (128 if nt <= 128 else 256)
             head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16), candidate tiles t %% %d == rank" % (
-                             kh, " x 2 blocks (256 + %d folded terms)" % (nt - 256) if nt > 256 else "", sj.T),
+                             kh, " (128 terms with a column each + %d folded into 128 columns)" % (nt - 128) if nt > 256 else "", sj.T),
                          "achieved": head_flops / (hm * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s (per GPU: the slowest rank's kernel and that rank's flops)",
                          "frac": head_flops / (hm * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None}

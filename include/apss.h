@@ -70,9 +70,11 @@ typedef struct apss_config {
                               library may pick 65536 (sparse regime, term shards with 8-bit accumulators) or 131072 rows
                               (sparser still) from the data: apss_stats.tiles says what it took */
   int32_t head_terms;      /* dense-head block: 0 = the library decides from the term distribution, -1 = never,
-                              64 | 128 | 256 | 512 | 1024 = always that many of the most frequent terms (512, 1024: two / four
-                              blocks of 256, each a part of its own under the candidate rule).  Terms in the block are scored
-                              by a bf16 MFMA contraction instead of their posting lists; results are the same set */
+                              N <= 8192 = always the N most frequent terms.  Up to 256 terms: a column each.  More: ONE block of
+                              256 columns, the 128 most frequent terms with a column each, the others FOLDED into the other 128
+                              (several terms add into one column: an upper bound of their partial score for non-negative
+                              weights).  Terms in the block are scored by a bf16 MFMA contraction instead of their posting
+                              lists; results are the same set */
   int64_t capacity_rows;   /* hints for the initial HBM reservation (0 = grow on demand) */
   int64_t capacity_nnz;
 } apss_config;
@@ -101,8 +103,7 @@ typedef struct apss_stats {
                                shard's or a sparse batch's rounds of a few hundred postings) */
   uint32_t downgrades;      /* APSS_DOWNGRADE_*: permanent fallbacks (until apss_clear) this handle took because of a call it could
                                not serve on its fast layout; each costs one full index rebuild when it happens */
-  uint32_t head_columns;    /* width of a row of the dense-head block at the last call: 64 | 128 | 256 for one block, 384 | 512 = 256 columns
-                               + a folded block of 128 | 256 (0: none) */
+  uint32_t head_columns;    /* width of a row of the dense-head block at the last call: 64 | 128 | 256 (0: none) */
   char probe_kernel[96];    /* the probe kernel instantiation the last query-type call launched, as rocprofv3 prints its name up
                                to the template arguments' spelling, e.g. "k_probe_even<512,6,128,0,0,0>" (threads, window steps,
                                long-segment list, shard rule, signed, 8-bit accumulators); "" before any probe */
@@ -185,7 +186,7 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
 
 
 /* ---- dense-head block set by the caller ----
- * The `n_terms` (<= 1024; more than 256: blocks of 256 in the order given) most frequent terms are scored by a bf16 MFMA contraction over W = [rows x n_terms] instead of
+ * The `n_terms` (<= 8192; more than 256: the first 128 with a column each, the others folded, in the order given) most frequent terms are scored by a bf16 MFMA contraction over W = [rows x n_terms] instead of
  * their posting lists (CommonUtils.scala:110-115 restricted to those dims; a FILTER: survivors are re-scored exactly).
  * On a plain handle this replaces the library's own choice (apss_config.head_terms).  On a TERM SHARD it is the only way
  * to get a block: every shard of a join must be given the SAME terms -- they are a part of their own, {H, T_1 .. T_T}, in
@@ -197,11 +198,9 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
  * apss_clear); the setting survives apss_clear; n_terms == 0 removes it.  Shards: non-negative weights, no
  * APSS_FLAG_ADMISSION (APSS_E_UNSUPPORTED otherwise). */
 int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *terms, int32_t part, int32_t n_parts);
-/* Columns of the FOLDED block (128 | 256; 0 = the default, 256) of a head of more than 256 terms set through
- * apss_set_head_terms: fewer columns make the second contraction cheaper and pass more chance pairs; the library's own
- * policy decides it on a sample, a caller that names the terms passes on what that sample justified (apss_stats.head_columns
- * of the handle that chose them, minus 256).  Shards of one join need not agree on it.  Before apss_set_head_terms, on an
- * empty handle. */
+/* How many of the 256 columns of a head of more than 256 terms are FOLDED columns (64 | 128 | 192; 0 = the default, 128):
+ * the 256 - columns most frequent terms keep a column each, the others add into the folded ones.  Takes effect at the next
+ * apss_set_head_terms; on an empty handle. */
 int32_t apss_set_head_fold(apss_handle *h, int32_t columns);
 /* the block's terms in block order (chosen by the library or set by the caller); *n_terms = how many there are */
 int32_t apss_get_head_terms(apss_handle *h, int32_t capacity, int32_t *out_terms, int32_t *n_terms);

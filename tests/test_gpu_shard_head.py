@@ -45,12 +45,12 @@ def test_term_shards_with_a_head_block_match_oracle(oracle, T, kh, n, dim, nnz, 
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
     assert len(want) > 100
     head, df = _top_terms(idx, dim, kh)
-    fold = 128 if (kh > 256 and T % 2 == 1) else 0  # (one case with the narrow folded block named by the caller)
+    fold = 192 if (kh > 256 and T % 2 == 1) else 0  # (one case with the split named by the caller: 64 terms with a column each + 192 folded columns)
     engines = _shard_engines(dim, theta, idx, T, head, rp=rp, val=val, tile_rows=1024, fold=fold)
     q, c, s, n_cand = join_shards_local(engines, n, theta)
     assert_same_pairs(to_map(q, c, s), want, theta)
     if kh > 256:
-        assert all(e.stats["head_columns"] == 256 + (fold or 256) for e in engines)
+        assert all(e.stats["head_columns"] == 256 for e in engines)
     tail_df = df.astype(np.int64).copy()
     tail_df[head] = 0
     # the block's terms are in no shard's index; every other posting is visited by exactly one shard
@@ -96,12 +96,12 @@ def test_c5_power_law_reduced_four_shards_policy_block(oracle):
     dim, theta, n = cfg["dim"], cfg["theta"], cfg["n"]
     head, fold = hip_head_chooser(dim, theta, torch.device("cuda", 0))(rp, idx, val)
     assert head.size in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and len(set(head.tolist())) == head.size
-    assert fold in (0, 128, 256) and (fold > 0) == (head.size > 256)
+    assert fold == 0  # (the library's default split)
     engines = _shard_engines(dim, theta, idx, 4, head, rp=rp, val=val, fold=fold)
     q, c, s, n_cand = join_shards_local(engines, n, theta)
     got = to_map(q, c, s)
     for e in engines:  # the folded block's width travelled with the terms
-        assert e.stats["head_columns"] == (256 + fold if head.size > 256 else e.stats["head_columns"])
+        assert e.stats["head_columns"] == (256 if head.size > 256 else e.stats["head_columns"])
     with ApssIndex(dim, theta, head_terms=-1) as ix:
         ref = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
     assert len(ref) > 1000
@@ -201,7 +201,7 @@ def test_set_head_terms_contract():
             ix.set_head_terms(head, 2, 2)
         assert e.value.code == _lib.E_INVALID
         with pytest.raises(ApssError) as e:
-            ix.set_head_terms(head, fold_columns=64)
+            ix.set_head_terms(head, fold_columns=100)
         assert e.value.code == _lib.E_INVALID
         ix.set_head_terms(head)  # cfg.head_terms = -1 forbids the POLICY, not the caller
         for _ in range(2):

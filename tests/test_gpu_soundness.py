@@ -225,16 +225,19 @@ def test_dense_head_filter_at_the_worst_case_of_bf16_rounding(engine, oracle):
     assert all(kq in want or abs(v - theta) <= 1e-5 for kq, v in got.items())
 
 
-@pytest.mark.parametrize("fold_w", [256, 128])
-def test_folded_head_block_at_the_worst_case_of_bf16_rounding(engine, oracle, monkeypatch, fold_w):
-    """the same attack on the FOLDED second block of a wide head (terms beyond the first 256 add into fold_w columns; its test
-    is an upper bound of the partial score only as long as rounding cannot take it below theta): pairs whose whole mass sits
-    on k equal entries among the FOLDED terms, each 1/sqrt(k) just below a bf16 rounding midpoint, scores a hair above
+@pytest.mark.parametrize("geometry", ["default", "fold_w=256", "fold_w=128", "mix=64"])
+def test_folded_head_columns_at_the_worst_case_of_bf16_rounding(engine, oracle, monkeypatch, geometry):
+    """the same attack on the FOLDED columns of a wide head (terms beyond the first `exact` add into shared columns; the test is
+    an upper bound of the head's partial score only as long as rounding cannot take it below theta): pairs whose whole mass
+    sits on k equal entries among the FOLDED terms, each 1/sqrt(k) just below a bf16 rounding midpoint, scores a hair above
     theta -- with the k terms chosen once in distinct columns (no collision helps) and once all in ONE column (a folded
-    column is a sum, rounded once).  All found, in both layouts"""
-    monkeypatch.setenv("APSS_DEBUG", "fold_w=%d" % fold_w)
+    column is a sum, rounded once).  All found: in the default geometry (one block: 128 + 128 folded columns), another
+    split of it, and the two-block forms kept for comparison"""
+    if geometry != "default":
+        monkeypatch.setenv("APSS_DEBUG", geometry)
+    exact, fold = {"default": (128, 128), "fold_w=256": (256, 256), "fold_w=128": (256, 128), "mix=64": (64, 192)}[geometry]
     k = max(range(8, 65), key=lambda kk: _bf16_round_down_loss(1.0 / np.sqrt(kk)))
-    dim, theta, n_head = 6000, 0.8, 256 + 4 * fold_w
+    dim, theta, n_head = 6000, 0.8, 256 + 4 * fold
     rng = np.random.default_rng(9)
     # the head is NAMED (apss_set_head_terms: terms 0 .. n_head-1 in this order, so the column of every folded term is known);
     # filler rows give every head term some postings
@@ -243,9 +246,10 @@ def test_folded_head_block_at_the_worst_case_of_bf16_rounding(engine, oracle, mo
         others = np.sort(rng.choice(np.arange(n_head, dim), size=6, replace=False))
         v = np.abs(rng.standard_normal(7)) + 0.1
         rows.append((np.concatenate([[t], others]), v / np.sqrt((v * v).sum())))
-    folded = np.arange(256, n_head)
-    spread = folded[:k]                                     # k folded terms in k different columns
-    stacked = folded[(folded - 256) % fold_w == 5][:4]      # four folded terms of ONE column
+    folded = np.arange(exact, n_head)
+    spread = folded[:k]                                       # k folded terms in k different columns
+    stacked = folded[(folded - exact) % fold == 5][:4]        # four folded terms of ONE column
+    assert spread.size == k and stacked.size == 4
     for terms in (spread, stacked):
         kk = terms.size
         for _ in range(20):
@@ -262,7 +266,7 @@ def test_folded_head_block_at_the_worst_case_of_bf16_rounding(engine, oracle, mo
         got = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
         st = ix.stats()
         assert ix.head_terms().tolist() == list(range(n_head))
-    assert st["head_terms"] == n_head and st["head_columns"] == 256 + fold_w and st["head_survivors"] >= len(near)
+    assert st["head_terms"] == n_head and st["head_columns"] == exact + fold and st["head_survivors"] >= len(near)
     missing = [kq for kq in want if kq not in got and abs(want[kq] - theta) > 1e-5]
     assert not missing, (len(missing), missing[:3])
     assert all(kq in want or abs(v - theta) <= 1e-5 for kq, v in got.items())
