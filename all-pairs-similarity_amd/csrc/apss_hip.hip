@@ -582,7 +582,8 @@ constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse 
 // profiles/r02_head_gemm.md: 1.65 PFLOP/s at 256; narrower blocks are bound by the epilogue's scan, not by the MFMAs)
 constexpr double kHeadDenseCost[4] = {1.5e-13, 1.9e-13, 3.1e-13, 3.1e-13};  // (last: a head of more than 256 terms -- still ONE block of 256 columns)
 constexpr double kHeadFoldMaxRowTerms = 96.0;  // terms of the folded block a row may hold on average (chance pairs collide in m^2 / 256 columns)
-constexpr double kHeadSurvivorCost = 1.0e-8;  // seconds per element the dense filter passes on (report + de-dup + exact re-score)
+constexpr double kHeadSurvivorCost = 2.5e-9;  // seconds per element the dense filter passes on (report + de-dup + exact re-score; measured in
+                                              // round 3: 5.6e6 more survivors cost 5 ms, i.e. 0.9e-9 each; the sample's TRUE pairs count too)
 
 // A plain handle decides for itself (choose_head) unless the block's terms were set through apss_set_head_terms; a term
 // shard only ever takes the terms it was given -- the {H, T_1 .. T_T} partition of the shard rule must be the same on every
@@ -685,7 +686,7 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
                  float thr, int64_t n_cand);
 
 // How selective is the dense filter on THIS data: the block's first rows (at most 8192) against its first 512 as queries,
-// counted, not stored.  Returns the fraction of (q, c != q) elements at or above the threshold.  (Rows arrive in no
+// stored and re-scored.  Returns the fraction of (q, c != q) elements the filter passes that do NOT reach theta.  (Rows arrive in no
 // particular order in the reference's stream -- ShardRegion routing is random, CommonUtils.scala:28-40 -- so a prefix is a
 // sample.)
 int32_t head_sample_selectivity(apss_handle *h, double *frac) {
@@ -716,9 +717,19 @@ int32_t head_sample_selectivity(apss_handle *h, double *frac) {
   p.fold_from = h->head_exact;
   hipLaunchKernelGGL(k_head_pack, dim3((unsigned)ceil_div(p.w_pad, 8)), dim3(512), 0, h->stream, p);
   HIPCHK(h, hipGetLastError());
+  // the sample's survivors are STORED and re-scored exactly: what counts against the block is what it passes in excess -- a
+  // pair that reaches theta is a survivor of every filter (the sample of a batch with planted near-duplicates holds 3e-5 of
+  // them: counted against the block they vetoed a head that halves the step of C3 with Zipf(0.5) terms)
+  constexpr size_t kSampleCap = 1 << 20;
+  APSS_TRY(ensure(h, h->res_q, kSampleCap));
+  APSS_TRY(ensure(h, h->res_c, kSampleCap));
+  APSS_TRY(ensure(h, h->res_s, kSampleCap));
   ProbeArgs a{};
   a.q_ext = h->ext.p;
-  a.res_cap = 0;  // count only
+  a.res_q = h->res_q.p;
+  a.res_c = h->res_c.p;
+  a.res_s = h->res_s.p;
+  a.res_cap = kSampleCap;
   a.counters = h->head_ctr.p + 2;
   const double bound = (double)h->store_max_norm2 * 1.0001 + 1e-6;  // |q||c| <= the largest squared row norm
   APSS_TRY(run_head(h, a, Q, -1, h->W.p, p.w_pad, (float)(h->cfg.theta - 0.0080 * bound - 1e-5), S));
@@ -726,7 +737,33 @@ int32_t head_sample_selectivity(apss_handle *h, double *frac) {
   HIPCHK(h, hipMemcpyAsync(c, h->head_ctr.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const double pairs = (double)Q * (double)S - (double)Q;
-  *frac = pairs > 0 ? (double)c[2] / pairs : 0.0;
+  unsigned long long n_true = 0;
+  if (c[2] > 0 && c[2] <= kSampleCap) {
+    APSS_TRY(ensure(h, h->fin_q, (size_t)c[2]));
+    APSS_TRY(ensure(h, h->fin_c, (size_t)c[2]));
+    APSS_TRY(ensure(h, h->fin_s, (size_t)c[2]));
+    HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, sizeof(unsigned long long), h->stream));
+    RescoreArgs r{};
+    r.n_pairs = (int64_t)c[2];
+    r.q_row = h->res_q.p;
+    r.c_slot = h->res_c.p;
+    r.q_rowptr = h->rowptr.p;  // (the sample's queries are the store's first rows)
+    r.q_idx = h->idx.p;
+    r.q_val = h->val.p;
+    r.c_rowptr = h->rowptr.p;
+    r.c_idx = h->idx.p;
+    r.c_val = h->val.p;
+    r.theta = (float)h->cfg.theta;
+    r.out_q = h->fin_q.p;
+    r.out_c = h->fin_c.p;
+    r.out_s = h->fin_s.p;
+    r.out_count = h->head_ctr.p;
+    hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(r.n_pairs * kGroup, 256)), dim3(256), 0, h->stream, r);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(&n_true, h->head_ctr.p, sizeof(n_true), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  *frac = pairs > 0 ? (double)(c[2] - std::min(n_true, c[2])) / pairs : 0.0;
   return APSS_OK;
 }
 
