@@ -20,22 +20,24 @@
 // re-scored exactly over the FULL rows by k_rescore (CommonUtils.scala:98-117) and pruned at theta
 // (IndexingWorkerActor.scala:93), exactly as the survivors of the plain two-pass join are.
 //
-// Wider heads = a second, FOLDED block.  The rule above holds for any partition of the terms, so the head may be two parts
-// H_1 (the 256 most frequent terms, one column each, as above) and H_2 (the next 256 F terms), each with its own rows
-// w_c^b = c_{H_b} |c| / |c_{H_b}| and its own test  w_q^b . w_c^b >= theta.  H_2's rows are FOLDED into 256 columns: term
-// number i of H_2 adds into column i mod 256, and the test uses the dot product of the folded rows.  With non-negative
-// weights that is an UPPER bound of the true partial dot over H_2 --
-//     sum_col (sum_{t in col} q_t) (sum_{t in col} c_t)  >=  sum_t q_t c_t        (the cross terms are >= 0)
-// -- so no pair the exact test would pass is lost, and what it passes in excess (two rows holding DIFFERENT terms of one
-// column) is bounded by the rows' other entries: a row holds m ~ 10-40 of H_2's terms, a chance pair collides in ~m^2/256
-// columns, each worth ~1/m of the block's cosine, i.e. ~m/256 in all -- far below theta.  Every candidate is re-scored
-// exactly anyway.  Cost: ONE more contraction of width 256, whatever F -- while the posting visits the inverted index keeps
-// fall like 1 / (256 (1 + F)) under a Zipfian term distribution, and with them the long segments the sparse filter is
-// slowest on.  (Several EXACT blocks of 256 were measured first: blocks 2..4 of a 1024-term head hold 2-6 terms of a row
-// each, rows with a single term of a block pair up at cosine 1, and the blocks passed 4e7 .. 1.5e9 chance pairs on C3 with
-// Zipf(1) terms -- thin blocks lose the rule's selectivity, folding restores it.  A single contraction of width 512 or 1024
-// would need the A fragments of 64 query slots x 1024 terms = 512 VGPRs per lane.)  W holds a row's two blocks side by side:
-// with the chunk-major tile layout a tile is 64 rows x 512 columns and block b is the contiguous 32-KB piece b of the tile.
+// Wider heads = FOLDED columns.  A head of more than 256 terms is still ONE block of 256 columns: the `exact` (128) most
+// frequent terms keep a column each, every further term i adds into column  exact + (i - exact) mod (256 - exact).  The row is
+//     w_c = c~ * |c| / |c_H|,   c~ = the mixed row (own columns + folded sums),  |c_H| = the TRUE norm of the head entries,
+// and the test is the same  w_q . w_c >= theta.  With non-negative weights the mixed dot product is an UPPER bound of the
+// true partial dot over H --
+//     sum_col (sum_{t in col} q_t) (sum_{t in col} c_t)  >=  sum_{t in col} q_t c_t        (the cross terms are >= 0)
+// -- so no pair the exact test would pass is lost; what it passes in excess (two rows holding DIFFERENT terms of one
+// column) is bounded by the rows' other entries: a row holds m ~ 30-60 folded terms, a chance pair collides in ~m^2/128
+// columns, each worth ~1/m^2-ish of the head's cosine -- 0.1-0.2 in all, far below theta; every candidate is re-scored exactly
+// anyway.  Cost: the contraction of a 256-term head, WHATEVER the number of terms -- while the posting visits the inverted
+// index keeps fall like 1 / K under a Zipfian term distribution, and with them the long segments the sparse filter is slowest
+// on.  profiles/microbench/mixed_block_model.py models the pass counts of the splits (128 + 128, 64 + 192 and even 0 + 256
+// pass only the true near-duplicates of a 30,000-row sample; 192 + 64 and every 128-column block pass 10x .. 1e5x more).
+// Round 3 went there in steps, each measured: several EXACT blocks of 256 under the "or" rule (blocks 2..4
+// hold 2-6 terms of a row, rows with a single term of a block pair up at cosine 1: 4e7 .. 1.5e9 chance pairs), then 256
+// exact columns + a SECOND block of 256 or 128 folded columns with its own test (APSS_DEBUG=fold_w=256|128 still builds
+// that form: k_head_gemm's `chunk0` / `kt` arguments address a block inside a wider row), then the one mixed block: ONE test
+// over the whole head is also more selective than the "or" of two.
 //
 // Rounding bound of the contraction: bf16 keeps 8 significant bits, round-to-nearest errs by <= 2^-8 relative, a
 // product of two rounded factors by <= 2^-7 + 2^-16, and sum_i |a_i b_i| <= |a||b| <= B (B = the largest |q||c| of the
@@ -83,8 +85,8 @@ __host__ __device__ __forceinline__ int64_t head_chunk_off(int64_t row, int chun
   return (((row >> 6) * (kh / 8) + chunk) * kHeadCTile + (row & 63)) * 8;
 }
 constexpr int kHeadBlock = 256;      // columns per block of a two-block head
-constexpr int kHeadMaxBlocks = 2;    // block 0: one column per term; block 1: the further terms folded into 128 or 256 columns
-constexpr int kHeadMaxFold = 31;     // terms per column of the folded block at most: heads of up to 256 * 32 = 8192 terms
+constexpr int kHeadMaxBlocks = 2;    // (the two-block experiment form: 256 columns + a block of folded columns with its own norm)
+constexpr int kHeadMaxFold = 31;     // heads of up to 256 * 32 = 8192 terms
 
 struct HeadPackArgs {
   const int64_t *rowptr;   // absolute offsets into idx / val
