@@ -113,3 +113,21 @@ def test_bench_two_ranks_skewed_terms_take_the_dense_head_block():
     m = [r for r in roofs if r["bound"] == "mfma"][0]
     assert 0 < m["frac"] < 1.0 and "k_head_gemm" in m["kernel"] and "% 2 == rank" in m["kernel"]
     assert d["candidate_range_layout"]["result_pairs_per_step"] == d["result_pairs_per_step"] > 100
+
+
+def test_bench_four_ranks_report_three_layouts():
+    """N = 4 rehearsal (gloo, four ranks on GPU 0): the contract's four term-range shards as `value`, the candidate-range layout
+    and the 2 x 2 grid (two term ranges x two candidate ranges, partial scores all-reduced inside each pair) beside it; the
+    three layouts report the same result set"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                          "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rows", "40000",
+                          "--steps", "2", "--warmup", "1", "--backend", "gloo", "--cpu-seconds", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _one_line(out)
+    assert d["n_gpus"] == 4 and "4 term-range shards x 1 candidate ranges" in d["config"]["parallelism"]
+    mid, comp = d["grid_2_term_ranges_layout"], d["candidate_range_layout"]
+    assert mid["grid"] == "2 term-range shards x 2 candidate ranges" and comp["grid"] == "1 term-range shards x 4 candidate ranges"
+    assert mid["result_pairs_per_step"] == comp["result_pairs_per_step"] == d["result_pairs_per_step"] > 0
+    assert mid["exchange"]["term_shards"] == 2 and mid["exchange"]["all_reduce_bytes"] > 0
