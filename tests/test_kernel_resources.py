@@ -24,7 +24,7 @@ def test_speed_kernels_keep_two_workgroups_per_cu(tmp_path):
             m = re.search(r"\s%s: (\d+)" % key, line)
             if m and cur:
                 res[cur][key.split(" ")[0]] = int(m.group(1))
-    checked = 0
+    checked = heads = 0
     for name, r in res.items():
         two_per_cu = ("k_probe_coarseILi512" in name) or ("k_probe_waveILi512ELi5" in name) or ("k_probe_evenILi512" in name)
         # the long-query instantiation (VROWS, the boolean after the chunk size) is allowed its 8 B/lane of scratch: it is
@@ -39,4 +39,10 @@ def test_speed_kernels_keep_two_workgroups_per_cu(tmp_path):
             checked += 1
         if "k_probe" in name:
             assert r["ScratchSize"] == 0, (name, r)
-    assert checked >= 4
+        if "k_head_gemm" in name:
+            # the dense-head contraction: one 8-wave workgroup per CU = two waves per SIMD needs <= 256 VGPRs, no scratch (the
+            # A fragments of 64 query slots alone are 128 of them at 256 columns), and its tile buffers + reporting scratch
+            # inside one CU's LDS
+            assert r["VGPRs"] <= 256 and r["ScratchSize"] == 0 and r["Occupancy"] >= 2 and r["LDS"] <= 160 * 1024, (name, r)
+            heads += 1
+    assert checked >= 4 and heads >= 4
