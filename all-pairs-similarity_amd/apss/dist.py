@@ -205,11 +205,11 @@ class ShardedJoin:
 
     def _decide_head(self, rp, idx, val):
         """rank 0 asks the policy, every rank gets the same terms (one broadcast at load time, not in the data path)"""
-        buf = torch.zeros(8194, dtype=torch.int32, device=self.comm)
+        buf = torch.zeros(32770, dtype=torch.int32, device=self.comm)
         if self.rank == 0:
             chosen = self.head_chooser(rp, idx, val)
             t, fold = chosen if isinstance(chosen, tuple) else (chosen, 0)  # (terms, columns of the folded block | 0)
-            t = np.asarray(t, dtype=np.int32)[:8192]
+            t = np.asarray(t, dtype=np.int32)[:32768]
             buf[0], buf[1] = int(t.size), int(fold)
             if t.size:
                 buf[2:2 + t.size] = torch.from_numpy(t).to(self.comm)

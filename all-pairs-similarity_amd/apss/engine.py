@@ -135,7 +135,7 @@ class ApssIndex:
 
     def head_terms(self):
         n = C.c_int32(0)
-        out = np.zeros(8192, np.int32)
+        out = np.zeros(32768, np.int32)
         self._chk(self._L.apss_get_head_terms(self._h, out.size, _ptr(out), C.byref(n)))
         return out[:n.value].copy()
 

@@ -86,7 +86,7 @@ __host__ __device__ __forceinline__ int64_t head_chunk_off(int64_t row, int chun
 }
 constexpr int kHeadBlock = 256;      // columns per block of a two-block head
 constexpr int kHeadMaxBlocks = 2;    // (the two-block experiment form: 256 columns + a block of folded columns with its own norm)
-constexpr int kHeadMaxFold = 31;     // heads of up to 256 * 32 = 8192 terms
+constexpr int kHeadMaxFold = 127;    // heads of up to 256 * 128 = 32768 terms
 
 struct HeadPackArgs {
   const int64_t *rowptr;   // absolute offsets into idx / val

@@ -800,7 +800,7 @@ int32_t choose_head(apss_handle *h, bool *changed) {
     size_t i = 0;
     int ki = 0;
     double m_fold = 0.0;  // average number of folded-block terms per row
-    for (int32_t kk : {64, 128, 256, 512, 1024, 2048, 4096, 8192}) {
+    for (int32_t kk : {64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768}) {
       if (kk > kHeadMaxTerms || (size_t)kk > top + 255) break;
       for (; i < std::min<size_t>(top, (size_t)kk); ++i) {
         const double f = (double)df[(size_t)order[i]] / (double)sampled;
@@ -2148,7 +2148,7 @@ int32_t apss_clear(apss_handle *h) {
 int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *terms, int32_t part, int32_t n_parts) {
   APSS_TRY(enter(h));
   if (h->n_rows != 0) return fail(h, APSS_E_STATE, "apss_set_head_terms: the handle holds vectors (set the block before the first insert or after apss_clear)");
-  if (n_terms < 0 || n_terms > kHeadMaxTerms || (n_terms > 0 && !terms)) return fail(h, APSS_E_INVALID, "apss_set_head_terms: 0 .. 8192 terms");
+  if (n_terms < 0 || n_terms > kHeadMaxTerms || (n_terms > 0 && !terms)) return fail(h, APSS_E_INVALID, "apss_set_head_terms: 0 .. 32768 terms");
   if (n_parts < 1 || part < 0 || part >= n_parts) return fail(h, APSS_E_INVALID, "apss_set_head_terms: part must be in [0, n_parts)");
   if (n_parts > 1 && !h->sharded)
     return fail(h, APSS_E_INVALID, "apss_set_head_terms: only a term shard multiplies a share of the block (n_parts > 1)");

@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--rows", "--n", dest="n", type=int, default=None, help="override the number of vectors (debug); "
                     "spell it --rows under torch.distributed.run, whose own parser claims every prefix of its options")
     ap.add_argument("--tile-rows", type=int, default=0)
-    ap.add_argument("--head-terms", type=int, default=0, help="dense-head block: 0 = the library's policy, -1 never, N <= 8192 = that many of the most frequent terms (beyond 256: folded block)")
+    ap.add_argument("--head-terms", type=int, default=0, help="dense-head block: 0 = the library's policy, -1 never, N <= 32768 = that many of the most frequent terms (beyond 256: folded block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-row", action="store_true", help="skip the fp32-accumulate sibling measurement")
     ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid of the headline layout (default: all ranks)")

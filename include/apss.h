@@ -70,7 +70,7 @@ typedef struct apss_config {
                               library may pick 65536 (sparse regime, term shards with 8-bit accumulators) or 131072 rows
                               (sparser still) from the data: apss_stats.tiles says what it took */
   int32_t head_terms;      /* dense-head block: 0 = the library decides from the term distribution, -1 = never,
-                              N <= 8192 = always the N most frequent terms.  Up to 256 terms: a column each.  More: ONE block of
+                              N <= 32768 = always the N most frequent terms.  Up to 256 terms: a column each.  More: ONE block of
                               256 columns, the 128 most frequent terms with a column each, the others FOLDED into the other 128
                               (several terms add into one column: an upper bound of their partial score for non-negative
                               weights).  Terms in the block are scored by a bf16 MFMA contraction instead of their posting
@@ -186,7 +186,7 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
 
 
 /* ---- dense-head block set by the caller ----
- * The `n_terms` (<= 8192; more than 256: the first 128 with a column each, the others folded, in the order given) most frequent terms are scored by a bf16 MFMA contraction over W = [rows x n_terms] instead of
+ * The `n_terms` (<= 32768; more than 256: the first 128 with a column each, the others folded, in the order given) most frequent terms are scored by a bf16 MFMA contraction over W = [rows x n_terms] instead of
  * their posting lists (CommonUtils.scala:110-115 restricted to those dims; a FILTER: survivors are re-scored exactly).
  * On a plain handle this replaces the library's own choice (apss_config.head_terms).  On a TERM SHARD it is the only way
  * to get a block: every shard of a join must be given the SAME terms -- they are a part of their own, {H, T_1 .. T_T}, in

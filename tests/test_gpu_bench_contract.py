@@ -55,7 +55,7 @@ def test_bench_skewed_workload_reports_an_mfma_roofline():
     d = _one_line(out)
     for k in DRIVER_KEYS:
         assert k in d, k
-    assert d["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and d["head_pairs_per_step"] > 0 and "bf16" in d["dtype"]
+    assert d["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768) and d["head_pairs_per_step"] > 0 and "bf16" in d["dtype"]
     roofs = [d["roofline"]] + [d[k] for k in ("roofline_sparse_filter", "roofline_dense_head") if k in d]
     assert len(roofs) == 2 and {r["bound"] for r in roofs} == {"lds", "mfma"}
     m = [r for r in roofs if r["bound"] == "mfma"][0]
@@ -107,7 +107,7 @@ def test_bench_two_ranks_skewed_terms_take_the_dense_head_block():
     d = _one_line(out)
     for k in DRIVER_KEYS:
         assert k in d, k
-    assert d["n_gpus"] == 2 and d["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and d["head_kernel_ms_slowest_rank"] > 0
+    assert d["n_gpus"] == 2 and d["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768) and d["head_kernel_ms_slowest_rank"] > 0
     roofs = [d["roofline"]] + [d[k] for k in ("roofline_sparse_filter", "roofline_dense_head") if k in d]
     assert len(roofs) == 2 and {r["bound"] for r in roofs} == {"lds", "mfma"}
     m = [r for r in roofs if r["bound"] == "mfma"][0]

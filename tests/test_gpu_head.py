@@ -101,7 +101,7 @@ def test_c2_size_zipf1_policy_and_forced_block(engine, oracle):
     ref, st0 = _join(engine, dim, theta, rp, idx, val, head_terms=-1)
     assert st0["head_terms"] == 0, st0
     auto, st_a = _join(engine, dim, theta, rp, idx, val)
-    assert st_a["head_terms"] in (0, 512, 1024, 2048, 4096, 8192) and auto.keys() == ref.keys()
+    assert st_a["head_terms"] in (0, 512, 1024, 2048, 4096, 8192, 16384, 32768) and auto.keys() == ref.keys()
     got, st = _join(engine, dim, theta, rp, idx, val, head_terms=256)
     assert st["head_terms"] == 256 and st["head_survivors"] > 100 * len(got)
     assert ref.keys() == got.keys() and len(got) > 1000
@@ -118,7 +118,7 @@ def test_c3_shape_zipf1_auto_policy(engine, oracle):
     cfg, rp, idx, val = synth.make_config("c3z1", n=60_000, device="cuda")
     dim, theta = cfg["dim"], cfg["theta"]
     got, st = _join(engine, dim, theta, rp, idx, val)
-    assert st["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and st["head_pairs"] > 0, st
+    assert st["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768) and st["head_pairs"] > 0, st
     ref, st0 = _join(engine, dim, theta, rp, idx, val, head_terms=-1)
     assert st0["head_terms"] == 0 and ref.keys() == got.keys() and len(got) > 1000
     assert st["posting_visits"] < st0["posting_visits"] // 10
@@ -139,7 +139,7 @@ def test_c5_power_law_reduced(engine, oracle):
     with engine.ApssIndex(dim, theta) as ix:
         got = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
         st = ix.stats()
-        assert st["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and st["head_pairs"] > 0.9 * n * (n - 1), st
+        assert st["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768) and st["head_pairs"] > 0.9 * n * (n - 1), st
         b0, b1 = 5000, 5600
         sl = slice(rp[b0], rp[b1])
         gq = to_map(*ix.query(np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl]))

@@ -95,7 +95,7 @@ def test_c5_power_law_reduced_four_shards_policy_block(oracle):
     cfg, rp, idx, val = synth.make_config("c5z", n=40_000, device="cuda")
     dim, theta, n = cfg["dim"], cfg["theta"], cfg["n"]
     head, fold = hip_head_chooser(dim, theta, torch.device("cuda", 0))(rp, idx, val)
-    assert head.size in (64, 128, 256, 512, 1024, 2048, 4096, 8192) and len(set(head.tolist())) == head.size
+    assert head.size in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768) and len(set(head.tolist())) == head.size
     assert fold == 0  # (the library's default split)
     engines = _shard_engines(dim, theta, idx, 4, head, rp=rp, val=val, fold=fold)
     q, c, s, n_cand = join_shards_local(engines, n, theta)
@@ -193,7 +193,7 @@ def test_set_head_terms_contract():
             ix.set_head_terms(head)
         assert e.value.code == _lib.E_STATE
         ix.clear()
-        for bad in ([1, 1], [dim], [-1], list(range(8193))):
+        for bad in ([1, 1], [dim], [-1], list(range(32769))):
             with pytest.raises(ApssError) as e:
                 ix.set_head_terms(bad)
             assert e.value.code == _lib.E_INVALID
