@@ -788,14 +788,31 @@ int32_t choose_head(apss_handle *h, bool *changed) {
   std::vector<int32_t> order((size_t)dim);
   for (int32_t t = 0; t < dim; ++t) order[(size_t)t] = t;
   const size_t top = (size_t)std::min<int32_t>(dim, kHeadMaxTerms);
-  std::partial_sort(order.begin(), order.begin() + (ptrdiff_t)top, order.end(),
-                    [&](int32_t x, int32_t y) { return df[(size_t)x] != df[(size_t)y] ? df[(size_t)x] > df[(size_t)y] : x < y; });
+  const auto more_frequent = [&](int32_t x, int32_t y) { return df[(size_t)x] != df[(size_t)y] ? df[(size_t)x] > df[(size_t)y] : x < y; };
+  bool hopeless = false;
+  if (h->cfg.head_terms == 0) {
+    // before sorting anything: no head of kHeadMaxTerms terms can save more visits than min(all terms', that many of the most
+    // frequent one's) -- on uniform data (C3: every benchmark step re-evaluates after its apss_clear) that is below the
+    // cheapest block's cost and the 3 ms of sorting 100k terms are not spent
+    double s2_all = 0.0, f_max = 0.0;
+    for (int32_t t = 0; t < dim; ++t) {
+      const double f = (double)df[(size_t)t] / (double)sampled;
+      s2_all += f * f;
+      f_max = std::max(f_max, f);
+    }
+    const double s2_bound = std::min(s2_all, (double)top * f_max * f_max);
+    hopeless = s2_bound / kHeadSparseRate < 1.5 * 0.5 * kHeadDenseCost[0];
+  }
+  if (!hopeless) {
+    std::nth_element(order.begin(), order.begin() + (ptrdiff_t)top - 1, order.end(), more_frequent);
+    std::sort(order.begin(), order.begin() + (ptrdiff_t)top, more_frequent);
+  }
   int32_t k = 0;
   double best_gain = 0.0;  // seconds per N^2 pairs the chosen block is expected to save
   double gain256 = 0.0;    // ... and a plain 256-term block, the fall-back when the folded block proves unselective
   if (h->cfg.head_terms > 0) {
     k = std::min(h->cfg.head_terms <= 256 ? head_width(h->cfg.head_terms, 0) : h->cfg.head_terms, kHeadMaxTerms);  // terms wanted
-  } else if (n >= kHeadMinRows) {
+  } else if (n >= kHeadMinRows && !hopeless) {
     double best = 0.0, s2 = 0.0;
     size_t i = 0;
     int ki = 0;
