@@ -1187,6 +1187,247 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
 // ---- probe the whole index with a query batch resident on the device ----
 // q_head: rows of the batch in the dense-head block (null when the handle has none): the store's W for a stored batch,
 // the staged q_W otherwise.
+// What a probe knows when it picks the filter kernel's instantiation (plan_filter)
+struct FilterFacts {
+  bool acc8;         // this call's norms and row lengths leave room for 8-bit sums over the handle's >= 65536-row tiles
+  bool shard_rule;   // term shard, or the sparse half of a handle with a dense-head block
+  bool sgn;          // weights of either sign: the filter sums the positive products
+  bool hybrid;       // the handle has a dense-head block
+  int64_t s_max_nnz, s_nnz_end;  // longest staged query row, elements staged
+  int64_t nq, idx_nnz;           // query rows, postings in the inverted index
+};
+
+// ---- which instantiation of the filter kernel: the register window (U steps of 8 chunks per wave) is sized for the
+// chunks a wave expects per round; a round's cost grows with U whether or not its slots hold postings, so thin rounds
+// (term shards: 1/T of a query's terms; sparse regimes: short segments) take a short window
+// Pure host arithmetic on what ingest and the index build measured; the choice is reported in apss_stats.probe_kernel.
+int32_t plan_filter(apss_handle *h, const FilterFacts &f, CxVariant &cxv, ProbeArgs &a) {
+  const DebugCfg &dbg = h->dbgcfg;
+  cxv.acc8 = f.acc8;
+  cxv.block = h->cx.cb > 65536 || (h->cx.cb > 32768 && !cxv.acc8) ? 1024 : 512;
+  cxv.shard = f.shard_rule;
+  cxv.chunk = dbg.chunk8 ? 8 : 16;
+  cxv.vrows = f.s_max_nnz > 512;
+  cxv.sgn = f.sgn;
+  const double nw = cxv.block / kWave;
+  const double seg = (double)h->cx.cb * ((double)f.idx_nnz / (double)h->n_rows) / (double)h->cfg.dim;  // postings per (tile, term)
+  double q_terms = (double)f.s_nnz_end / (double)f.nq;
+  // a shard holds a binomial share of each query's terms; a window that overflows costs a whole-tile clear, so the
+  // shard-rule launches size it for the upper end (3 sigma) and for segments one chunk longer than their mean
+  const double t_hi = f.shard_rule ? q_terms + 3.0 * std::sqrt(q_terms) : q_terms;
+  const double wave_chunks = std::ceil(t_hi / nw - 1e-9) * std::max(1.0, seg / 16.0 + (f.shard_rule ? 1.0 : 0.5));
+  int u = (int)std::ceil(wave_chunks * (f.shard_rule ? 1.0 : 1.05) / 8.0);
+  if (cxv.block == 1024) u = (q_terms / nw) * std::max(1.0, seg / 16.0 + 0.5) <= 17.0 && !dbg.big_u5 ? 3 : 5;
+  else u = std::max(2, std::min(5, u));
+  if (cxv.vrows || cxv.sgn) u = cxv.block == 1024 ? u : 5;
+  if (dbg.chunk8) u = 4;
+  if (dbg.window && cxv.block == 512 && !cxv.vrows && !cxv.sgn) u = dbg.window;
+  // the skewed tail of a handle with a dense-head block: full window, prefetched long sweeps.  (A term shard's tail range
+  // may hold no long segment at all once the block has taken the frequent terms: it then runs like any other shard)
+  const bool long_tail = f.hybrid && h->cx.max_seg > (uint32_t)kLongLenW && !cxv.acc8;
+  if (long_tail && !dbg.window) {
+    u = 5;
+    cxv.longpf = true;
+  }
+  if (cxv.vrows && cxv.shard && !cxv.sgn) {  // long rows (real TF-IDF) on a term shard: the shard-rule instantiation that takes virtual rows
+    u = 5;
+    cxv.longpf = true;
+  }
+  if (dbg.longpf && cxv.block == 512 && !cxv.vrows && !cxv.sgn && !cxv.acc8) {
+    u = 5;
+    cxv.longpf = true;
+  }
+  cxv.u = u;
+  // k_probe_even (apss_even.hpp): F waves stage the round, the others add an even share of its chunks -- a wave's window
+  // then holds a 1/A share of the ROUND's chunks, not the chunks of the wave's own terms.
+  // Staging lanes per term: as many as keep the staging waves at <= a quarter of the workgroup.
+  int flat_group_log2 = 2;
+  while (flat_group_log2 > 0 && ceil_div(f.s_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
+  if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
+  const int64_t flat_waves = std::max<int64_t>(1, ceil_div(f.s_max_nnz, kWave >> flat_group_log2));
+  // Where it is taken (measured on C3 and its shards, ms of the filter kernel, k_probe_even vs k_probe_coarse): term shards
+  // T = 8: 23.4 vs 40.5, T = 4: 35.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 58.7 vs 77.9; the sparse
+  // regime's 1024-thread kernel (C5's shape at a fifth of N): 218.2 vs 291.5; the plain handle of C3 itself (100-term rows,
+  // LDS-throughput-bound): 100.6 vs 111.3 with six adding waves x 6 steps, 115.4 with 7 steps -- a plain 512-thread handle
+  // takes it when its adding waves issue no more window steps per round than k_probe_coarse's eight would.
+  const bool wide_ok = f.shard_rule || cxv.block == 1024 || dbg.even_wide;
+  // (not where long segments abound -- more than 16 long terms per tile: the thin-round kernel sweeps them on its rare
+  // path, meant for one round in a few.  C3 with Zipf(0.5) terms, ~400 long terms per tile and half a dozen in every round,
+  // measured 1395 ms there against 518 ms on k_probe_coarse)
+  const bool few_longs = (double)h->cx.long_segs <= 16.0 * (double)std::max<int64_t>(1, h->cx.n_tiles) || f.shard_rule || cxv.block == 1024;
+  if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4 && few_longs) {
+    CxVariant ev = cxv;
+    ev.even = true;
+    const double add_waves = nw - (double)flat_waves;               // a wave that stages a round adds nothing in it
+    // postings per (tile, term) over the terms this handle indexes (a term shard: its range, not the whole dimension)
+    const double seg_here = seg * (double)h->cfg.dim / (double)std::max<int64_t>(1, (int64_t)h->cfg.term_hi - h->cfg.term_lo);
+    const double cpt = std::max(1.0, seg_here / 16.0 + 0.5);      // chunks per term
+    // (mean + 2 sigma of a binomial share of the terms: the rounds beyond read their last chunks from the strip and end
+    // with a whole-tile clear, ~2 % of them; at 3 sigma the T = 8 shard took a 3-step window: 24.8 vs 23.2 ms)
+    double round_chunks = q_terms * cpt + 2.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
+    // ... that is the uniform-terms estimate; the index build MEASURED what an average stored row deals out per tile
+    // (sum over terms of P(term in the row) x chunks of its segment): under a skewed distribution the terms a query holds
+    // are the ones with the long segments, and the estimate above falls short by a factor (power-law C5's tail: 85
+    // estimated, 200 dealt out: most rounds overflowed their window, a whole-tile clear each)
+    if (h->cx.round_chunks > 0.0) {
+      const double per_term = std::max(1.0, h->cx.round_chunks / std::max(1.0, q_terms));
+      round_chunks = std::max(round_chunks, h->cx.round_chunks + 2.0 * std::sqrt(h->cx.round_chunks * per_term));
+    }
+    // (a plain handle's rows are whole rows: no binomial share of the terms; the longest row bounds the round)
+    if (!f.shard_rule) round_chunks = std::min(round_chunks, 1.05 * (double)f.s_max_nnz * cpt);
+    int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
+    // (a window that overflows most rounds pays a whole-tile clear each time)
+    const bool fits = ue <= 7 && !cxv.sgn && (wide_ok || add_waves * std::max(2, ue) <= nw * (double)cxv.u);
+    ue = cxv.block == 1024 ? (ue <= 3 ? 3 : std::max(5, ue)) : std::max(2, ue);
+    ev.u = ue;
+    if (dbg.diag)
+      fprintf(stderr, "[apss diag] even? block %d u %d | F %lld G %d A %.0f chunks %.1f ue %d fits %d exists %d q_max %lld q_terms %.1f seg %.1f\n", cxv.block, cxv.u,
+              (long long)flat_waves, 1 << flat_group_log2, add_waves, round_chunks, ue, (int)fits, (int)cx_variant_exists(ev), (long long)f.s_max_nnz, q_terms, seg);
+    if (fits && cx_variant_exists(ev)) {
+      cxv = ev;
+      a.flat_waves = (int32_t)flat_waves;
+      a.flat_group_log2 = flat_group_log2;
+    }
+  }
+  if (!cx_variant_exists(cxv)) return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
+  return APSS_OK;
+}
+
+// Queries of more terms than a round of the filter takes (512) are cut into parts that share the accumulators: part v covers
+// elements vrow_ptr[v] .. vrow_ptr[v + 1]) of query vrow_q[v]; vq_first[q] is query q's first part.
+int32_t cut_long_queries(apss_handle *h, const int64_t *s_rowptr, int64_t nq, int vrow_part, ProbeArgs &a) {
+  // queries of more terms than a round takes: cut them into parts that share the accumulators
+  APSS_TRY(ensure(h, h->vrow_np, (size_t)nq + 1));
+  APSS_TRY(ensure(h, h->vrow_first, (size_t)nq + 2));
+  APSS_TRY(ensure(h, h->vq_first, (size_t)nq + 1));
+  hipLaunchKernelGGL(k_vrow_count, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, h->stream, s_rowptr, nq, vrow_part, h->vrow_np.p);
+  APSS_TRY(scan_i64(h, (const int64_t *)h->vrow_np.p, h->vrow_first.p, nq));
+  HIPCHK(h, hipGetLastError());
+  int64_t nv = 0;
+  HIPCHK(h, hipMemcpyAsync(&nv, h->vrow_first.p + nq, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  APSS_TRY(ensure(h, h->vrow_ptr, (size_t)nv + 1));
+  APSS_TRY(ensure(h, h->vrow_q, (size_t)nv + 1));
+  hipLaunchKernelGGL(k_vrow_fill, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, h->stream, s_rowptr, nq, vrow_part,
+                     (const int64_t *)h->vrow_first.p, h->vq_first.p, h->vrow_ptr.p, h->vrow_q.p);
+  HIPCHK(h, hipGetLastError());
+  a.vq_first = h->vq_first.p;
+  a.vrow_ptr = h->vrow_ptr.p;
+  a.vrow_q = h->vrow_q.p;
+  return APSS_OK;
+}
+
+// The exact pass of the two-pass join: the filters' survivors (h->res_*, h->n_res of them; with a dense-head block a pair may
+// be there twice) are re-scored from the fp32 store and pruned at theta (k_rescore); then the rows that still wait outside the
+// index are scored against every query, pair by pair (k_tail_score).  Leaves the final list in h->fin_* / h->n_res.
+int32_t exact_pass(apss_handle *h, bool hybrid, double theta, int64_t nq, const int64_t *q_rowptr, const int32_t *q_idx,
+                   const float *q_val, const int64_t *q_ext, int64_t tail_n) {
+  float ms = 0.f;
+  // exact pass: re-score what the filter(s) let through from the fp32 store and prune at theta
+  int64_t n_cand = h->n_res;
+  h->st.filter_survivors = n_cand;
+  h->n_res = 0;
+  const int32_t *cand_q = h->res_q.p, *cand_c = h->res_c.p;
+  if (hybrid && n_cand > 0) {
+    // a pair that passed both filters is in the list twice
+    uint64_t tab = 1024;
+    while (tab < (uint64_t)n_cand * 2) tab <<= 1;
+    APSS_TRY(ensure(h, h->dedup_tab, (size_t)tab, 0, true));
+    APSS_TRY(ensure(h, h->uq_q, (size_t)n_cand, 0, true));
+    APSS_TRY(ensure(h, h->uq_c, (size_t)n_cand, 0, true));
+    APSS_TRY(ensure(h, h->uq_s, (size_t)n_cand, 0, true));
+    HIPCHK(h, hipMemsetAsync(h->dedup_tab.p, 0xff, (size_t)tab * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(k_pair_dedup, dim3((unsigned)ceil_div(n_cand, 256)), dim3(256), 0, h->stream,
+                       (const int32_t *)h->res_q.p, (const int32_t *)h->res_c.p, (const float *)h->res_s.p, n_cand,
+                       h->dedup_tab.p, tab - 1, h->uq_q.p, h->uq_c.p, h->uq_s.p, h->counters.p);
+    HIPCHK(h, hipGetLastError());
+    unsigned long long nu = 0;
+    HIPCHK(h, hipMemcpyAsync(&nu, h->counters.p, sizeof(nu), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    n_cand = (int64_t)nu;
+    cand_q = h->uq_q.p;
+    cand_c = h->uq_c.p;
+  }
+  if (n_cand > 0) {
+    APSS_TRY(ensure(h, h->fin_q, (size_t)n_cand, 0, true));
+    APSS_TRY(ensure(h, h->fin_c, (size_t)n_cand, 0, true));
+    APSS_TRY(ensure(h, h->fin_s, (size_t)n_cand, 0, true));
+    HIPCHK(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
+    RescoreArgs r{};
+    r.n_pairs = n_cand;
+    r.q_row = cand_q;
+    r.c_slot = cand_c;
+    r.q_rowptr = q_rowptr;
+    r.q_idx = q_idx;
+    r.q_val = q_val;
+    r.c_rowptr = h->rowptr.p;
+    r.c_idx = h->idx.p;
+    r.c_val = h->val.p;
+    r.theta = (float)theta;
+    r.out_q = h->fin_q.p;
+    r.out_c = h->fin_c.p;
+    r.out_s = h->fin_s.p;
+    r.out_count = h->counters.p;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    // (a launch may not have 2^32 threads or more: 16 lanes per pair -> at most 2^27 pairs per launch)
+    for (int64_t p0 = 0; p0 < n_cand; p0 += (1LL << 27)) {
+      RescoreArgs rr = r;
+      rr.n_pairs = std::min<int64_t>(1LL << 27, n_cand - p0);
+      rr.q_row = cand_q + p0;
+      rr.c_slot = cand_c + p0;
+      hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(rr.n_pairs * kGroup, 256)), dim3(256), 0, h->stream, rr);
+      HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    unsigned long long nfin = 0;
+    HIPCHK(h, hipMemcpyAsync(&nfin, h->counters.p, sizeof(nfin), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->st.rescore_ms = ms;
+    h->n_res = (int64_t)nfin;
+  }
+  if (tail_n > 0) {
+    // the rows that wait outside the index: every (query, tail row) pair, exactly (k_tail_score)
+    const int64_t pairs = nq * tail_n;
+    APSS_TRY(ensure(h, h->fin_q, (size_t)(h->n_res + pairs), (size_t)h->n_res));
+    APSS_TRY(ensure(h, h->fin_c, (size_t)(h->n_res + pairs), (size_t)h->n_res));
+    APSS_TRY(ensure(h, h->fin_s, (size_t)(h->n_res + pairs), (size_t)h->n_res));
+    HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
+    TailArgs t{};
+    t.nq = nq;
+    t.n_tail = tail_n;
+    t.q_rowptr = q_rowptr;
+    t.q_idx = q_idx;
+    t.q_val = q_val;
+    t.q_ext = q_ext;
+    t.c_rowptr = h->rowptr.p;
+    t.c_idx = h->idx.p;
+    t.c_val = h->val.p;
+    t.c_ext = h->ext.p;
+    t.tail0 = h->idx_rows;
+    t.theta = (float)theta;
+    t.out_q = h->fin_q.p;
+    t.out_c = h->fin_c.p;
+    t.out_s = h->fin_s.p;
+    t.out_base = h->n_res;
+    t.counters = h->counters.p;
+    hipLaunchKernelGGL(k_tail_score, dim3((unsigned)ceil_div(pairs * kGroup, 256)), dim3(256), 0, h->stream, t);
+    HIPCHK(h, hipGetLastError());
+    unsigned long long tc[kCtrCount];
+    HIPCHK(h, hipMemcpyAsync(tc, h->counters.p, sizeof(tc), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->n_res += (int64_t)tc[kCtrResults];
+    h->st.posting_visits += (int64_t)tc[kCtrVisits];
+    h->st.candidate_pairs += (int64_t)tc[kCtrCands];
+  }
+  h->out_q = h->fin_q.p;
+  h->out_c = h->fin_c.p;
+  h->out_s = h->fin_s.p;
+  h->st.result_pairs = h->n_res;
+  return APSS_OK;
+}
+
 int32_t pack_query_head(apss_handle *h, const int64_t *rowptr, const int32_t *idx, const float *val, int64_t nq);
 
 // q_slot_first: slot of query row 0 when the batch is rows of the store (self-join, insert-and-query), else -1.
@@ -1374,99 +1615,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::max(1.0, std::ceil(theta * scale_used)));
   a.theta_fxi = (int32_t)std::max(-2147483647.0, std::min(2147483647.0, std::ceil(theta * scale_used)));
 
-  // ---- which instantiation of the filter kernel: the register window (U steps of 8 chunks per wave) is sized for the
-  // chunks a wave expects per round; a round's cost grows with U whether or not its slots hold postings, so thin rounds
-  // (term shards: 1/T of a query's terms; sparse regimes: short segments) take a short window
   CxVariant cxv{};
-  if (coarse_path) {
-    cxv.acc8 = a8_scale > 0;
-    cxv.block = h->cx.cb > 65536 || (h->cx.cb > 32768 && !cxv.acc8) ? 1024 : 512;
-    cxv.shard = shard_rule;
-    cxv.chunk = dbg.chunk8 ? 8 : 16;
-    cxv.vrows = s_max_nnz > 512;
-    cxv.sgn = cx_signed;
-    const double nw = cxv.block / kWave;
-    const double seg = (double)h->cx.cb * ((double)idx_nnz / (double)h->n_rows) / (double)h->cfg.dim;  // postings per (tile, term)
-    double q_terms = (double)s_nnz_end / (double)nq;
-    // a shard holds a binomial share of each query's terms; a window that overflows costs a whole-tile clear, so the
-    // shard-rule launches size it for the upper end (3 sigma) and for segments one chunk longer than their mean
-    const double t_hi = shard_rule ? q_terms + 3.0 * std::sqrt(q_terms) : q_terms;
-    const double wave_chunks = std::ceil(t_hi / nw - 1e-9) * std::max(1.0, seg / 16.0 + (shard_rule ? 1.0 : 0.5));
-    int u = (int)std::ceil(wave_chunks * (shard_rule ? 1.0 : 1.05) / 8.0);
-    if (cxv.block == 1024) u = (q_terms / nw) * std::max(1.0, seg / 16.0 + 0.5) <= 17.0 && !dbg.big_u5 ? 3 : 5;
-    else u = std::max(2, std::min(5, u));
-    if (cxv.vrows || cxv.sgn) u = cxv.block == 1024 ? u : 5;
-    if (dbg.chunk8) u = 4;
-    if (dbg.window && cxv.block == 512 && !cxv.vrows && !cxv.sgn) u = dbg.window;
-    // the skewed tail of a handle with a dense-head block: full window, prefetched long sweeps.  (A term shard's tail range
-    // may hold no long segment at all once the block has taken the frequent terms: it then runs like any other shard)
-    const bool long_tail = hybrid_wanted && h->cx.max_seg > (uint32_t)kLongLenW && !cxv.acc8;
-    if (long_tail && !dbg.window) {
-      u = 5;
-      cxv.longpf = true;
-    }
-    if (cxv.vrows && cxv.shard && !cxv.sgn) {  // long rows (real TF-IDF) on a term shard: the shard-rule instantiation that takes virtual rows
-      u = 5;
-      cxv.longpf = true;
-    }
-    if (dbg.longpf && cxv.block == 512 && !cxv.vrows && !cxv.sgn && !cxv.acc8) {
-      u = 5;
-      cxv.longpf = true;
-    }
-    cxv.u = u;
-    // k_probe_even (apss_even.hpp): F waves stage the round, the others add an even share of its chunks -- a wave's window
-    // then holds a 1/A share of the ROUND's chunks, not the chunks of the wave's own terms.
-    // Staging lanes per term: as many as keep the staging waves at <= a quarter of the workgroup.
-    int flat_group_log2 = 2;
-    while (flat_group_log2 > 0 && ceil_div(s_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
-    if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
-    const int64_t flat_waves = std::max<int64_t>(1, ceil_div(s_max_nnz, kWave >> flat_group_log2));
-    // Where it is taken (measured on C3 and its shards, ms of the filter kernel, k_probe_even vs k_probe_coarse): term shards
-    // T = 8: 23.4 vs 40.5, T = 4: 35.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 58.7 vs 77.9; the sparse
-    // regime's 1024-thread kernel (C5's shape at a fifth of N): 218.2 vs 291.5; the plain handle of C3 itself (100-term rows,
-    // LDS-throughput-bound): 100.6 vs 111.3 with six adding waves x 6 steps, 115.4 with 7 steps -- a plain 512-thread handle
-    // takes it when its adding waves issue no more window steps per round than k_probe_coarse's eight would.
-    const bool wide_ok = shard_rule || cxv.block == 1024 || dbg.even_wide;
-    // (not where long segments abound -- more than 16 long terms per tile: the thin-round kernel sweeps them on its rare
-    // path, meant for one round in a few.  C3 with Zipf(0.5) terms, ~400 long terms per tile and half a dozen in every round,
-    // measured 1395 ms there against 518 ms on k_probe_coarse)
-    const bool few_longs = (double)h->cx.long_segs <= 16.0 * (double)std::max<int64_t>(1, h->cx.n_tiles) || shard_rule || cxv.block == 1024;
-    if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4 && few_longs) {
-      CxVariant ev = cxv;
-      ev.even = true;
-      const double add_waves = nw - (double)flat_waves;               // a wave that stages a round adds nothing in it
-      // postings per (tile, term) over the terms this handle indexes (a term shard: its range, not the whole dimension)
-      const double seg_here = seg * (double)h->cfg.dim / (double)std::max<int64_t>(1, (int64_t)h->cfg.term_hi - h->cfg.term_lo);
-      const double cpt = std::max(1.0, seg_here / 16.0 + 0.5);      // chunks per term
-      // (mean + 2 sigma of a binomial share of the terms: the rounds beyond read their last chunks from the strip and end
-      // with a whole-tile clear, ~2 % of them; at 3 sigma the T = 8 shard took a 3-step window: 24.8 vs 23.2 ms)
-      double round_chunks = q_terms * cpt + 2.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
-      // ... that is the uniform-terms estimate; the index build MEASURED what an average stored row deals out per tile
-      // (sum over terms of P(term in the row) x chunks of its segment): under a skewed distribution the terms a query holds
-      // are the ones with the long segments, and the estimate above falls short by a factor (power-law C5's tail: 85
-      // estimated, 200 dealt out: most rounds overflowed their window, a whole-tile clear each)
-      if (ix.round_chunks > 0.0) {
-        const double per_term = std::max(1.0, ix.round_chunks / std::max(1.0, q_terms));
-        round_chunks = std::max(round_chunks, ix.round_chunks + 2.0 * std::sqrt(ix.round_chunks * per_term));
-      }
-      // (a plain handle's rows are whole rows: no binomial share of the terms; the longest row bounds the round)
-      if (!shard_rule) round_chunks = std::min(round_chunks, 1.05 * (double)s_max_nnz * cpt);
-      int ue = (int)std::ceil(round_chunks / (8.0 * add_waves));
-      // (a window that overflows most rounds pays a whole-tile clear each time)
-      const bool fits = ue <= 7 && !cxv.sgn && (wide_ok || add_waves * std::max(2, ue) <= nw * (double)cxv.u);
-      ue = cxv.block == 1024 ? (ue <= 3 ? 3 : std::max(5, ue)) : std::max(2, ue);
-      ev.u = ue;
-      if (dbg.diag)
-        fprintf(stderr, "[apss diag] even? block %d u %d | F %lld G %d A %.0f chunks %.1f ue %d fits %d exists %d q_max %lld q_terms %.1f seg %.1f\n", cxv.block, cxv.u,
-                (long long)flat_waves, 1 << flat_group_log2, add_waves, round_chunks, ue, (int)fits, (int)cx_variant_exists(ev), (long long)s_max_nnz, q_terms, seg);
-      if (fits && cx_variant_exists(ev)) {
-        cxv = ev;
-        a.flat_waves = (int32_t)flat_waves;
-        a.flat_group_log2 = flat_group_log2;
-      }
-    }
-    if (!cx_variant_exists(cxv)) return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
-  }
+  if (coarse_path)
+    APSS_TRY(plan_filter(h, FilterFacts{a8_scale > 0, shard_rule, cx_signed, hybrid_wanted, s_max_nnz, s_nnz_end, nq, idx_nnz}, cxv, a));
   const int vrow_part = 512;
   // (the filter kernels keep their LDS in static arrays: no dynamic allocation)
   const size_t lds = coarse_path ? 0
@@ -1493,26 +1644,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     return APSS_OK;
   };
 
-  if (coarse_path && s_max_nnz > vrow_part) {
-    // queries of more terms than a round takes: cut them into parts that share the accumulators
-    APSS_TRY(ensure(h, h->vrow_np, (size_t)nq + 1));
-    APSS_TRY(ensure(h, h->vrow_first, (size_t)nq + 2));
-    APSS_TRY(ensure(h, h->vq_first, (size_t)nq + 1));
-    hipLaunchKernelGGL(k_vrow_count, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, h->stream, s_rowptr, nq, vrow_part, h->vrow_np.p);
-    APSS_TRY(scan_i64(h, (const int64_t *)h->vrow_np.p, h->vrow_first.p, nq));
-    HIPCHK(h, hipGetLastError());
-    int64_t nv = 0;
-    HIPCHK(h, hipMemcpyAsync(&nv, h->vrow_first.p + nq, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    APSS_TRY(ensure(h, h->vrow_ptr, (size_t)nv + 1));
-    APSS_TRY(ensure(h, h->vrow_q, (size_t)nv + 1));
-    hipLaunchKernelGGL(k_vrow_fill, dim3((unsigned)ceil_div(nq + 1, 256)), dim3(256), 0, h->stream, s_rowptr, nq, vrow_part,
-                       (const int64_t *)h->vrow_first.p, h->vq_first.p, h->vrow_ptr.p, h->vrow_q.p);
-    HIPCHK(h, hipGetLastError());
-    a.vq_first = h->vq_first.p;
-    a.vrow_ptr = h->vrow_ptr.p;
-    a.vrow_q = h->vrow_q.p;
-  }
+  if (coarse_path && s_max_nnz > vrow_part) APSS_TRY(cut_long_queries(h, s_rowptr, nq, vrow_part, a));
   // one launch sweeps a group of tiles sized for roughly 2e11 posting visits (a few hundred ms): a very large join
   // becomes a sequence of launches of bounded duration instead of one kernel that runs for tens of seconds
   const int64_t total_tiles = ix.n_tiles;
@@ -1655,110 +1787,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     h->out_c = h->res_c.p;
     h->out_s = h->res_s.p;
     if (coarse_path && h->sharded) h->st.filter_survivors = h->n_res;  // a shard's survivors are its candidates (phase 2 scores them)
-    if (coarse_path && !h->sharded) {
-      // exact pass: re-score what the filter(s) let through from the fp32 store and prune at theta
-      int64_t n_cand = h->n_res;
-      h->st.filter_survivors = n_cand;
-      h->n_res = 0;
-      const int32_t *cand_q = h->res_q.p, *cand_c = h->res_c.p;
-      if (hybrid && n_cand > 0) {
-        // a pair that passed both filters is in the list twice
-        uint64_t tab = 1024;
-        while (tab < (uint64_t)n_cand * 2) tab <<= 1;
-        APSS_TRY(ensure(h, h->dedup_tab, (size_t)tab, 0, true));
-        APSS_TRY(ensure(h, h->uq_q, (size_t)n_cand, 0, true));
-        APSS_TRY(ensure(h, h->uq_c, (size_t)n_cand, 0, true));
-        APSS_TRY(ensure(h, h->uq_s, (size_t)n_cand, 0, true));
-        HIPCHK(h, hipMemsetAsync(h->dedup_tab.p, 0xff, (size_t)tab * sizeof(unsigned long long), h->stream));
-        HIPCHK(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(k_pair_dedup, dim3((unsigned)ceil_div(n_cand, 256)), dim3(256), 0, h->stream,
-                           (const int32_t *)h->res_q.p, (const int32_t *)h->res_c.p, (const float *)h->res_s.p, n_cand,
-                           h->dedup_tab.p, tab - 1, h->uq_q.p, h->uq_c.p, h->uq_s.p, h->counters.p);
-        HIPCHK(h, hipGetLastError());
-        unsigned long long nu = 0;
-        HIPCHK(h, hipMemcpyAsync(&nu, h->counters.p, sizeof(nu), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        n_cand = (int64_t)nu;
-        cand_q = h->uq_q.p;
-        cand_c = h->uq_c.p;
-      }
-      if (n_cand > 0) {
-        APSS_TRY(ensure(h, h->fin_q, (size_t)n_cand, 0, true));
-        APSS_TRY(ensure(h, h->fin_c, (size_t)n_cand, 0, true));
-        APSS_TRY(ensure(h, h->fin_s, (size_t)n_cand, 0, true));
-        HIPCHK(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
-        RescoreArgs r{};
-        r.n_pairs = n_cand;
-        r.q_row = cand_q;
-        r.c_slot = cand_c;
-        r.q_rowptr = q_rowptr;
-        r.q_idx = q_idx;
-        r.q_val = q_val;
-        r.c_rowptr = h->rowptr.p;
-        r.c_idx = h->idx.p;
-        r.c_val = h->val.p;
-        r.theta = (float)theta;
-        r.out_q = h->fin_q.p;
-        r.out_c = h->fin_c.p;
-        r.out_s = h->fin_s.p;
-        r.out_count = h->counters.p;
-        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-        // (a launch may not have 2^32 threads or more: 16 lanes per pair -> at most 2^27 pairs per launch)
-        for (int64_t p0 = 0; p0 < n_cand; p0 += (1LL << 27)) {
-          RescoreArgs rr = r;
-          rr.n_pairs = std::min<int64_t>(1LL << 27, n_cand - p0);
-          rr.q_row = cand_q + p0;
-          rr.c_slot = cand_c + p0;
-          hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(rr.n_pairs * kGroup, 256)), dim3(256), 0, h->stream, rr);
-          HIPCHK(h, hipGetLastError());
-        }
-        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-        unsigned long long nfin = 0;
-        HIPCHK(h, hipMemcpyAsync(&nfin, h->counters.p, sizeof(nfin), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        h->st.rescore_ms = ms;
-        h->n_res = (int64_t)nfin;
-      }
-      if (tail_n > 0) {
-        // the rows that wait outside the index: every (query, tail row) pair, exactly (k_tail_score)
-        const int64_t pairs = nq * tail_n;
-        APSS_TRY(ensure(h, h->fin_q, (size_t)(h->n_res + pairs), (size_t)h->n_res));
-        APSS_TRY(ensure(h, h->fin_c, (size_t)(h->n_res + pairs), (size_t)h->n_res));
-        APSS_TRY(ensure(h, h->fin_s, (size_t)(h->n_res + pairs), (size_t)h->n_res));
-        HIPCHK(h, hipMemsetAsync(h->counters.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
-        TailArgs t{};
-        t.nq = nq;
-        t.n_tail = tail_n;
-        t.q_rowptr = q_rowptr;
-        t.q_idx = q_idx;
-        t.q_val = q_val;
-        t.q_ext = q_ext;
-        t.c_rowptr = h->rowptr.p;
-        t.c_idx = h->idx.p;
-        t.c_val = h->val.p;
-        t.c_ext = h->ext.p;
-        t.tail0 = h->idx_rows;
-        t.theta = (float)theta;
-        t.out_q = h->fin_q.p;
-        t.out_c = h->fin_c.p;
-        t.out_s = h->fin_s.p;
-        t.out_base = h->n_res;
-        t.counters = h->counters.p;
-        hipLaunchKernelGGL(k_tail_score, dim3((unsigned)ceil_div(pairs * kGroup, 256)), dim3(256), 0, h->stream, t);
-        HIPCHK(h, hipGetLastError());
-        unsigned long long tc[kCtrCount];
-        HIPCHK(h, hipMemcpyAsync(tc, h->counters.p, sizeof(tc), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->n_res += (int64_t)tc[kCtrResults];
-        h->st.posting_visits += (int64_t)tc[kCtrVisits];
-        h->st.candidate_pairs += (int64_t)tc[kCtrCands];
-      }
-      h->out_q = h->fin_q.p;
-      h->out_c = h->fin_c.p;
-      h->out_s = h->fin_s.p;
-      h->st.result_pairs = h->n_res;
-    }
+    if (coarse_path && !h->sharded) APSS_TRY(exact_pass(h, hybrid, theta, nq, q_rowptr, q_idx, q_val, q_ext, tail_n));
     if (n_results) *n_results = h->n_res;
     return APSS_OK;
   }
