@@ -9,6 +9,7 @@ SO_PATH = os.path.join(CSRC, "libapss_hip.so")
 
 OK, E_INVALID, E_NOMEM, E_DEVICE, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 FLAG_VALUE_PRUNE, FLAG_ADMISSION, FLAG_NORMALIZE, FLAG_FORCE_SCAN, FLAG_FORCE_GENERAL, FLAG_EXACT_ACCUM = 1, 2, 4, 8, 16, 32
+FLAG_NO_SYMMETRY = 64
 
 # every symbol include/apss.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -34,7 +35,8 @@ class Stats(C.Structure):
                 ("filter_survivors", C.c_int64), ("rescore_ms", C.c_double),
                 ("head_terms", C.c_int64), ("head_pairs", C.c_int64), ("head_survivors", C.c_int64),
                 ("head_ms", C.c_double), ("head_flops", C.c_double), ("thin_launches", C.c_int64),
-                ("downgrades", C.c_uint32), ("head_columns", C.c_uint32), ("probe_kernel", C.c_char * 96)]
+                ("downgrades", C.c_uint32), ("head_columns", C.c_uint32), ("probe_kernel", C.c_char * 96),
+                ("device_posting_visits", C.c_int64), ("symmetric", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 def build_sources():

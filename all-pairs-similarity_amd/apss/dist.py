@@ -258,15 +258,15 @@ class ShardedJoin:
             # candidate ranges only: the handle's answer is final; count it without bringing the pairs to the host
             n_mine = self.engine.join()
             st = self.engine.stats
-            tot = torch.tensor([float(st.get("posting_visits", 0)), float(st.get("candidate_pairs", 0)), float(n_mine)],
-                               dtype=torch.float64, device=self.comm)
+            tot = torch.tensor([float(st.get("posting_visits", 0)), float(st.get("candidate_pairs", 0)), float(n_mine),
+                                float(st.get("device_posting_visits", st.get("posting_visits", 0)))], dtype=torch.float64, device=self.comm)
             if self.world > 1:
                 dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             self.last = {
                 "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
                 "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
                 "head_terms": st.get("head_terms", 0),
-                "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
+                "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()), "device_posting_visits": int(tot[3].item()),
                 "exchange": {"term_shards": 1, "candidate_ranges": self.D, "candidates_per_rank": [int(n_mine)],
                              "union": int(n_mine), "all_gather_bytes_per_rank": 0, "all_reduce_bytes": 0,
                              "term_ranges": self.ranges},
@@ -295,15 +295,15 @@ class ShardedJoin:
         st = getattr(self.engine, "stats", {}) or {}
         # whole-job counters: posting visits and touched pairs add up over all ranks; result pairs over the D groups
         mine = float(keep.sum().item()) if self.ti == 0 else 0.0
-        tot = torch.tensor([float(st.get("posting_visits", 0)), float(st.get("candidate_pairs", 0)), mine],
-                           dtype=torch.float64, device=self.comm)
+        tot = torch.tensor([float(st.get("posting_visits", 0)), float(st.get("candidate_pairs", 0)), mine,
+                            float(st.get("device_posting_visits", st.get("posting_visits", 0)))], dtype=torch.float64, device=self.comm)
         if self.world > 1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         self.last = {
             "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
             "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
             "head_terms": int(self.head.size),
-            "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()),
+            "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()), "device_posting_visits": int(tot[3].item()),
             "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes,
                          "union": int(uniq.numel()), "all_gather_bytes_per_rank": 8 * max(sizes + [1]) * self.T,
                          "all_reduce_bytes": 4 * int(uniq.numel()), "term_ranges": self.ranges,

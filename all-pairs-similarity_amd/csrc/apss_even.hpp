@@ -90,6 +90,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const int v0 = chunk * a.q_chunk;
   const int v1 = min(a.nq, v0 + a.q_chunk);
   const int nv = a.nq;
+  const int qtile = v0 / cb;  // (symmetric joins: the chunk lies inside one tile)
+  if (a.tri && tile > qtile) return;  // the mirrored half (ProbeArgs::tri): before any barrier, the whole workgroup
   const int64_t tile_row0 = (int64_t)tile * cb;
   const uint32_t lo = (uint32_t)(ln % LPC);
   const float cxs = a.cx_scale;
@@ -516,8 +518,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   atomicAdd(&stat[1], (unsigned long long)my_cands);
   __syncthreads();
   if (tid == 0) {
-    atomicAdd(&a.counters[kCtrVisits], stat[0]);
-    atomicAdd(&a.counters[kCtrCands], stat[1]);
+    const unsigned long long twice = a.tri && tile < qtile ? 2ull : 1ull;  // (both counts are symmetric in the two tiles)
+    atomicAdd(&a.counters[kCtrVisits], stat[0] * twice);
+    atomicAdd(&a.counters[kCtrCands], stat[1] * twice);
+    atomicAdd(&a.counters[kCtrDevVisits], stat[0]);
   }
 }
 

@@ -56,6 +56,7 @@ struct DebugCfg {
   int seg_align = 0;           // seg_align=N    postings per aligned unit of the coarse index (16 | 32)
   bool bank_order = false;     // bank_order     experiment: bank-aware posting order inside short segments (k_seg_bank_order)
   int fold_w = 0;              // fold_w=N       columns of the dense head's folded block (128 | 256)
+  bool no_sym = false;         // no_sym         as APSS_FLAG_NO_SYMMETRY
   int mix = 0;                 // mix=E          ONE head block of 256 columns: E terms with a column each, the others folded into 256 - E
 };
 
@@ -95,6 +96,7 @@ DebugCfg parse_debug_env() {
     else if (key == "bank_order") d.bank_order = val != 0;
     else if (key == "fold_w") d.fold_w = val;
     else if (key == "mix") d.mix = val;
+    else if (key == "no_sym") d.no_sym = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -1419,6 +1421,7 @@ int32_t exact_pass(apss_handle *h, bool hybrid, double theta, int64_t nq, const 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_res += (int64_t)tc[kCtrResults];
     h->st.posting_visits += (int64_t)tc[kCtrVisits];
+    h->st.device_posting_visits += (int64_t)tc[kCtrVisits];
     h->st.candidate_pairs += (int64_t)tc[kCtrCands];
   }
   h->out_q = h->fin_q.p;
@@ -1442,6 +1445,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->last_nq = nq;
   h->n_res = 0;
   h->st.posting_visits = h->st.candidate_pairs = h->st.result_pairs = 0;
+  h->st.device_posting_visits = 0;
+  h->st.symmetric = 0;
   h->st.probe_ms = 0;
   h->st.probe_launches = 0;
   h->st.thin_launches = 0;
@@ -1618,6 +1623,26 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   CxVariant cxv{};
   if (coarse_path)
     APSS_TRY(plan_filter(h, FilterFacts{a8_scale > 0, shard_rule, cx_signed, hybrid_wanted, s_max_nnz, s_nnz_end, nq, idx_nnz}, cxv, a));
+  // ---- SYMMETRIC whole-store join: the batch IS the indexed store (query row v = stored row v: apss_self_join, or
+  // insert-and-query into an empty handle), so the pair (q, c) and the pair (c, q) share their terms and their score.  The
+  // filter runs a (query tile S, candidate tile T) workgroup only for T <= S and k_mirror_survivors adds the other direction
+  // of every survivor with T < S; both directions are then re-scored exactly, as without the symmetry: same result list,
+  // half the rounds.  Needs query chunks that do not straddle a tile (q_chunk | cb).  The reference finds both directions by
+  // probing twice (IndexingWorkerActor.scala:123-134); posting_visits / candidate_pairs keep counting what IT visits (the
+  // kernels count a tile pair below the diagonal twice: both statistics are symmetric in the two tiles), and
+  // device_posting_visits says what the kernels visited.
+  bool tri = false;
+  if (coarse_path && !cxv.vrows && !dbg.no_sym && !(h->cfg.flags & APSS_FLAG_NO_SYMMETRY) && q_slot_base == 0 && nq == h->idx_rows &&
+      nq == h->n_rows && tail_n == 0 && ix.n_tiles > 1) {
+    int64_t qc = 1;
+    while (qc < a.q_chunk) qc <<= 1;
+    if (qc <= ix.cb && ix.cb % qc == 0) {
+      tri = true;
+      a.tri = 1;
+      a.q_chunk = (int32_t)qc;
+      a.n_chunks = (int32_t)ceil_div(nq, qc);
+    }
+  }
   const int vrow_part = 512;
   // (the filter kernels keep their LDS in static arrays: no dynamic allocation)
   const size_t lds = coarse_path ? 0
@@ -1725,6 +1750,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
         else APSS_TRY((launch_probe<2, false>(h, a, lds)));
       }
     }  // tile groups
+    if (tri) {
+      HIPCHK(h, hipMemcpyAsync(h->counters.p + kCtrSnap, h->counters.p + kCtrResults, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+      hipLaunchKernelGGL(k_mirror_survivors, dim3(1024), dim3(256), 0, h->stream, a.res_q, a.res_c, a.res_s,
+                         (const unsigned long long *)(h->counters.p + kCtrSnap), (uint64_t)a.res_cap, (int32_t)a.cb, h->counters.p + kCtrResults);
+      HIPCHK(h, hipGetLastError());
+    }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     unsigned long long sparse_results = 0, head_c[4] = {0, 0, 0, 0};
     if (hybrid) {
@@ -1746,6 +1777,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     h->st.probe_launches += n_launches;
     h->st.thin_launches += thin_launches;
     h->st.posting_visits = (int64_t)c[kCtrVisits];
+    h->st.device_posting_visits = (int64_t)(tri ? c[kCtrDevVisits] : c[kCtrVisits]);
+    h->st.symmetric = tri ? 1u : 0u;
     h->st.candidate_pairs = (int64_t)c[kCtrCands];
     // the speed paths count a stored query's touch of its own slot; it is not a (q, c != q) pair
     if ((wave_path || coarse_path) && q_slot_base >= 0)

@@ -42,7 +42,9 @@ __device__ __forceinline__ T uniform_load(const T *p) {
   return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
 }
 
-enum Counter { kCtrResults = 0, kCtrVisits = 1, kCtrCands = 2, kCtrFlags = 3, kCtrCount = 4 };
+// (kCtrDevVisits: posting visits the kernels actually made -- a symmetric whole-store join counts the mirrored half of
+// kCtrVisits / kCtrCands without visiting it; kCtrSnap: the survivor count before k_mirror_survivors appends)
+enum Counter { kCtrResults = 0, kCtrVisits = 1, kCtrCands = 2, kCtrFlags = 3, kCtrDevVisits = 4, kCtrSnap = 5, kCtrCount = 6 };
 
 // ---------------------------------------------------------------------------------------------------------
 // wavefront ballot / prefix-sum compaction: every active lane with `pred` gets a distinct slot of a global list
@@ -610,6 +612,9 @@ struct ProbeArgs {
   int32_t n_chunks;
   int32_t flat_waves;       // k_probe_even: waves that stage a round = ceil(longest query row / (64 / lanes per term))
   int32_t flat_group_log2;  // k_probe_even: log2 of the staging lanes per term (0, 1 or 2)
+  int32_t tri;              // SYMMETRIC whole-store join (filter kernels): query row v is stored row v and q_chunk divides cb; a
+                            // workgroup whose candidate tile lies ABOVE its queries' tile leaves at once, one BELOW counts its
+                            // statistics twice, and k_mirror_survivors adds (c, q) for every survivor (q, c) of such a tile pair
   int64_t q_slot_base;      // slot of query row 0 when the batch is stored in the index, else -1
   float theta;
   float fx_scale;     // fixed-point accumulators: 1.0 is this many units (2^30 or 2^28), k_probe_wave
@@ -1512,6 +1517,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const int chunk = blockIdx.x % a.n_chunks;
   const int q0 = chunk * a.q_chunk;
   const int q1 = min(a.nq, q0 + a.q_chunk);
+  const int qtile = q0 / a.cb;  // (symmetric joins: the chunk lies inside one tile)
+  if (a.tri && tile > qtile) return;  // the mirrored half: the workgroup (qtile, the chunks of this tile's rows) finds these pairs
   // rounds run over VIRTUAL rows: a query of more than BLOCK terms is cut into parts of <= BLOCK terms that share
   // the accumulators (the adds of all parts land before the query's candidates are cleared); without a table a
   // virtual row is a query
@@ -1974,8 +1981,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   atomicAdd(&stat[1], (unsigned long long)my_cands + (ln == 0 ? wave_cands : 0u));
   __syncthreads();
   if (tid == 0) {
-    atomicAdd(&a.counters[kCtrVisits], stat[0]);
-    atomicAdd(&a.counters[kCtrCands], stat[1]);
+    const unsigned long long twice = a.tri && tile < qtile ? 2ull : 1ull;  // (both counts are symmetric in the two tiles)
+    atomicAdd(&a.counters[kCtrVisits], stat[0] * twice);
+    atomicAdd(&a.counters[kCtrCands], stat[1] * twice);
+    atomicAdd(&a.counters[kCtrDevVisits], stat[0]);
   }
 }
 
@@ -2146,6 +2155,37 @@ __global__ void k_partial_scores(PartialArgs a) {
   }
   for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
   if (gl == 0) a.out[pair] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_mirror_survivors: the second half of a SYMMETRIC whole-store join (ProbeArgs::tri).  The filter kernels skipped every
+// workgroup whose candidate tile lies above its queries' tile; a survivor (q, c) with c's tile BELOW q's tile stands for the
+// pair (c, q) too -- the filter sums are upper bounds in either direction, so a true pair survives in the direction that was
+// run, and both directions are re-scored exactly afterwards (k_rescore / the shard's phase 2), each in its own order of
+// summation, exactly as without the symmetry.  Pairs inside one tile were found in both directions by the kernels themselves.
+// n_before: the survivor count when the filter launches ended (a copy: `counter` grows while this kernel appends).
+__global__ void k_mirror_survivors(int32_t *res_q, int32_t *res_c, float *res_s, const unsigned long long *n_before, uint64_t cap,
+                                   int32_t cb, unsigned long long *counter) {
+  const uint64_t n = min((uint64_t)*n_before, cap);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += stride) {  // (uniform per workgroup: wave_append)
+    const uint64_t i = base + threadIdx.x;
+    int32_t q = 0, c = 0;
+    float sc = 0.f;
+    bool m = false;
+    if (i < n) {
+      q = res_q[i];
+      c = res_c[i];
+      sc = res_s[i];
+      m = c / cb < q / cb;
+    }
+    const uint64_t o = wave_append(m, counter);
+    if (m && o < cap) {
+      res_q[o] = c;
+      res_c[o] = q;
+      res_s[o] = sc;
+    }
+  }
 }
 
 }  // namespace apss

@@ -191,7 +191,11 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
     sec_per_step = dt / a.steps
     visits, cands, launches = st["posting_visits"], st["candidate_pairs"], max(1, st["probe_launches"])
     probe_s, head_s = mean("probe_ms") * 1e-3, mean("head_ms") * 1e-3
-    alg_bytes = BYTES_PER_VISIT * visits
+    # the roofline is priced on the visits the KERNELS made: a whole-store join is symmetric (the library runs the filter over
+    # the tile pairs on or below the diagonal and mirrors the survivors; `visits` / `cands` keep counting what the reference's
+    # two-directional probe visits and scores -- see "symmetric_join" in the line)
+    dev_visits = st["device_posting_visits"]
+    alg_bytes = BYTES_PER_VISIT * dev_visits
     hybrid = st["head_terms"] > 0
     filter_kernel = st.get("probe_kernel", "")
     if filter_kernel.startswith("k_probe_even"):
@@ -202,6 +206,7 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
         "value": cands / sec_per_step,
         "ms_per_step": sec_per_step * 1e3,
         "posting_visits_per_step": visits,
+        "device_posting_visits_per_step": dev_visits,
         "candidate_pairs_per_step": cands,
         "result_pairs_per_step": int(n_pairs),
         "posting_visits_per_s": visits / sec_per_step,
@@ -256,6 +261,24 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
             out["roofline"], out["roofline_dense_head"] = sparse_roof, head_roof
     else:
         out["roofline"] = sparse_roof
+    if st["symmetric"] and not a.no_exact_row:
+        # the same join with every pair probed in BOTH directions, as the reference does it (APSS_FLAG_NO_SYMMETRY): same result
+        # list, measured beside the headline so that the line carries both
+        wd.phase = "two-directional sibling"
+        dt3, n3, per3 = run(_lib.FLAG_NO_SYMMETRY, max(1, min(2, a.steps)), 1)
+        s3 = per3[-1]
+        ps3 = float(np.mean([s["probe_ms"] for s in per3])) * 1e-3
+        assert int(n3) == int(n_pairs) and s3["candidate_pairs"] == cands and s3["posting_visits"] == visits, "the symmetric join disagrees with the two-directional probe"
+        out["symmetric_join"] = {
+            "note": "the batch is the whole store, so (q, c) and (c, q) share terms and score: the filter kernels run the (query "
+                    "tile, candidate tile) pairs on or below the diagonal, the survivors of the pairs below it are mirrored, and "
+                    "BOTH directions are re-scored exactly (same result list, same statistics: `value` counts the candidate "
+                    "pairs of the join as the reference scores them; the device made device_posting_visits_per_step visits)",
+            "device_share_of_posting_visits": dev_visits / visits if visits else None,
+            "two_directional": {"value": cands / (dt3 / len(per3)), "ms_per_step": dt3 / len(per3) * 1e3, "probe_kernel_ms": ps3 * 1e3,
+                                "frac": BYTES_PER_VISIT * visits / ps3 / 1e9 / HBM_PEAK_GBS if ps3 > 0 else None,
+                                "flag": "APSS_FLAG_NO_SYMMETRY"},
+        }
     # the fp32-everywhere sibling: single-pass kernel with exact u32 / fp32 accumulators, 8-B postings (what `frac`
     # means literally); measured in the same run so that the line carries both
     if not a.no_exact_row and not hybrid:
@@ -334,7 +357,8 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
                             "each term group, all-reduce of counters over all ranks" if sj.T > 1 else
                             "per step: all-reduce of counters only (result sets of different candidate ranges are disjoint)"),
         }
-        visits = sj.last["posting_visits"]
+        visits = sj.last.get("device_posting_visits", sj.last["posting_visits"])  # (what the kernels visited: a whole-store shard join is symmetric)
+        row["device_posting_visits_per_step"] = visits
         sparse_roof = {"bound": "lds", "kernel": sj.last.get("probe_kernel") or "k_probe_coarse",
                        "achieved": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 if pm > 0 else None,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s (per GPU: slowest shard's kernel, 1/N of the job's 8-B posting visits)",
@@ -464,12 +488,12 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
         print(json.dumps({"solo_shard": a.solo, "ms_per_step": dt * 1e3, "probe_kernel_ms": eng.stats["probe_ms"],
-                          "build_ms": eng.stats["build_ms"], "posting_visits": eng.stats["posting_visits"],
+                          "build_ms": eng.stats["build_ms"], "posting_visits": eng.stats["posting_visits"], "device_posting_visits": eng.stats["device_posting_visits"],
                           "candidates": int(n_c), "probe_kernel": eng.stats["probe_kernel"], "head_terms": eng.stats["head_terms"],
                           "head_ms": eng.stats["head_ms"], "head_survivors": eng.stats["head_survivors"],
                           "head_frac_of_bf16_peak": (eng.stats["head_flops"] / (eng.stats["head_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
                                                      if eng.stats["head_ms"] > 0 else None),
-                          "algorithmic_frac": BYTES_PER_VISIT * eng.stats["posting_visits"] / (eng.stats["probe_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}))
+                          "algorithmic_frac": BYTES_PER_VISIT * eng.stats["device_posting_visits"] / (eng.stats["probe_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}))
         wd.done()
         return
 

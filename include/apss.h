@@ -51,6 +51,9 @@ extern "C" {
 #define APSS_FLAG_FORCE_SCAN 8u  /* always use the general accumulator-scan kernel (the theta <= 0 path) */
 #define APSS_FLAG_FORCE_GENERAL 16u /* never use the per-wave speed path of the probe (test hook) */
 #define APSS_FLAG_EXACT_ACCUM 32u   /* single-pass join with exact accumulators only: no coarse filter + rescoring pass */
+#define APSS_FLAG_NO_SYMMETRY 64u    /* a whole-store join (apss_self_join, insert-and-query into an empty handle) probes every
+                                       pair in BOTH directions like the reference (IWA:123-134) instead of running the
+                                       filter over half of the tile pairs and mirroring its survivors; same results */
 
 typedef struct apss_handle apss_handle;
 
@@ -107,6 +110,11 @@ typedef struct apss_stats {
   char probe_kernel[96];    /* the probe kernel instantiation the last query-type call launched, as rocprofv3 prints its name up
                                to the template arguments' spelling, e.g. "k_probe_even<512,6,128,0,0,0>" (threads, window steps,
                                long-segment list, shard rule, signed, 8-bit accumulators); "" before any probe */
+  int64_t device_posting_visits; /* posting visits the kernels of the last call actually made: equal to posting_visits except
+                                    on a symmetric whole-store join, where posting_visits / candidate_pairs keep counting what
+                                    the reference's two-directional probe visits and the device visits about half of it */
+  uint32_t symmetric;       /* 1: the last call ran as a symmetric whole-store join (see APSS_FLAG_NO_SYMMETRY) */
+  uint32_t reserved0;
 } apss_stats;
 
 #define APSS_DOWNGRADE_ACC8 1u /* 8-bit accumulators over 65536 / 131072-row tiles given up (a long row, a large norm, an

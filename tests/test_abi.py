@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(so):
 
 def test_config_struct_matches_header():
     assert ctypes.sizeof(_lib.Config) == 64
-    assert ctypes.sizeof(_lib.Stats) == 248
+    assert ctypes.sizeof(_lib.Stats) == 264
 
 
 def test_no_cpu_fallback(so):
