@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--head-terms", type=int, default=0, help="dense-head block: 0 = the library's policy, -1 never, N <= 32768 = that many of the most frequent terms (beyond 256: folded block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-row", action="store_true", help="skip the fp32-accumulate sibling measurement")
+    ap.add_argument("--no-two-directional-row", action="store_true", help="skip the APSS_FLAG_NO_SYMMETRY sibling measurement "
+                                                                            "(profiling runs: its launches carry the headline kernel's name)")
     ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid of the headline layout (default: all ranks)")
     ap.add_argument("--solo", default=None, help="T,D,i,j: time shard (term i of T, rows j of D) alone on this GPU (projection)")
     ap.add_argument("--no-comparison-row", action="store_true", help="skip the candidate-range layout of multi-GPU runs")
@@ -261,7 +263,7 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
             out["roofline"], out["roofline_dense_head"] = sparse_roof, head_roof
     else:
         out["roofline"] = sparse_roof
-    if st["symmetric"] and not a.no_exact_row:
+    if st["symmetric"] and not a.no_exact_row and not a.no_two_directional_row:
         # the same join with every pair probed in BOTH directions, as the reference does it (APSS_FLAG_NO_SYMMETRY): same result
         # list, measured beside the headline so that the line carries both
         wd.phase = "two-directional sibling"

@@ -9,8 +9,9 @@ OUT=gpurun_out/r03/$W
 mkdir -p $OUT
 B="python3 bench.py --workload $W $@"
 $B --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1; echo "trace rc=$?"
-P="--steps 1 --warmup 0 --no-cpu-baseline"
+# (the traced and counted runs skip the two-directional sibling: its launches carry the headline kernel's name)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-two-directional-row > $OUT/trace.log 2>&1; echo "trace rc=$?"
+P="--steps 1 --warmup 0 --no-cpu-baseline --no-two-directional-row"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B $P > $OUT/pmc_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B $P > $OUT/pmc_write.log 2>&1; echo "write rc=$?"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmc_l2 -- $B $P > $OUT/pmc_l2.log 2>&1; echo "l2 rc=$?"

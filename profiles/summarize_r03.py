@@ -84,7 +84,7 @@ def main(workloads):
                 e["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cu_cycles * 4)
             out["kernels"][label] = e
         flt = out["kernels"].get("filter", {})
-        ent = {"algorithmic_bytes_per_launch": 8 * bench["posting_visits_per_step"] // max(1, bench["roofline"].get("launches", 1)
+        ent = {"algorithmic_bytes_per_launch": 8 * bench.get("device_posting_visits_per_step", bench["posting_visits_per_step"]) // max(1, bench["roofline"].get("launches", 1)
                                                                                           if bench["roofline"]["bound"] == "lds" else 1)}
         if "traffic_bytes_per_launch_corrected" in flt:
             ent["traffic_bytes_per_launch_corrected"] = flt["traffic_bytes_per_launch_corrected"]
