@@ -528,6 +528,13 @@ def main():
         }
         out.update(body)
         out.update(extra)
+        sym = out.get("symmetric_join")
+        if sym:  # spelled out at the top level: what `value` counts, and the same join without the symmetry
+            out["value_counts"] = ("candidate pairs of the join as the reference scores them (both directions of every pair) per second of "
+                                   "step wall time; a whole-batch join is symmetric and the device probes each tile pair once "
+                                   "(symmetric_join; APSS_FLAG_NO_SYMMETRY = value_two_directional)")
+            out["value_two_directional"] = sym["two_directional"]["value"]
+            out["ms_per_step_two_directional"] = sym["two_directional"]["ms_per_step"]
         if not a.no_cpu_baseline:
             wd.phase = "cpu baseline"
             out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 6.0))
