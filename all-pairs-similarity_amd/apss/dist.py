@@ -172,8 +172,10 @@ class ShardedJoin:
     T term shards share a candidate range and combine their partial scores with an all-reduce inside their group
     (the exchange the term-sharded index needs); the D candidate ranges are independent (their result sets are
     disjoint).  A term shard has 1/T of the posting visits of every (query, tile) round but the same number of rounds,
-    so its speed-up trails T (measured one shard at a time, T = 8 is 4.2x one GPU before the exchange,
-    eight candidate ranges 6.0x); candidate ranges need no data-path collective.  `term_shards` = T picks the layout:
+    so its speed-up trails T; candidate ranges need no data-path collective.  A shard that holds ALL rows (D = 1) joins its
+    batch symmetrically (half the rounds), a row-range cell meets its queries as an outside batch and
+    does not: measured one shard at a time on uniform C3, T = 8 is 3.8x one GPU before the exchange, eight candidate ranges
+    3.3x (section 7).  `term_shards` = T picks the layout:
     bench.py's headline is T = world (the layout BASELINE.json names), this class's default T = 1.
     head_terms: dense-head block of the term-sharded layouts (module docstring): 0 = the library's policy decides on rank 0,
     -1 = never, 64 | 128 | 256 | 512 | 1024 = that many of the most frequent terms.  (With T = 1 every handle is a plain one and decides
