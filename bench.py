@@ -406,7 +406,8 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
         "posting_visits_per_step": head["posting_visits_per_step"], "candidate_pairs_per_step": cands,
         "result_pairs_per_step": head["result_pairs_per_step"],
         "posting_visits_per_s": head["posting_visits_per_step"] / (head["ms_per_step"] * 1e-3),
-        "algorithmic_GBps_whole_step": BYTES_PER_VISIT * head["posting_visits_per_step"] / (head["ms_per_step"] * 1e-3) / 1e9,
+        "device_posting_visits_per_step": head["device_posting_visits_per_step"],  # (all ranks; a whole-store shard join is symmetric)
+        "algorithmic_GBps_whole_step": BYTES_PER_VISIT * head["device_posting_visits_per_step"] / (head["ms_per_step"] * 1e-3) / 1e9,
         "build_ms": head["build_ms_slowest_shard"], "probe_kernel_ms": head["probe_kernel_ms_slowest_shard"],
         "roofline": head["roofline"],
     }
@@ -535,6 +536,10 @@ def main():
                                    "(symmetric_join; APSS_FLAG_NO_SYMMETRY = value_two_directional)")
             out["value_two_directional"] = sym["two_directional"]["value"]
             out["ms_per_step_two_directional"] = sym["two_directional"]["ms_per_step"]
+        elif out.get("device_posting_visits_per_step", out.get("posting_visits_per_step")) != out.get("posting_visits_per_step"):
+            out["value_counts"] = ("candidate pairs of the join as the reference scores them (both directions of every pair) per second of "
+                                   "step wall time; shards that hold all rows join their batch symmetrically (DESIGN.md 5c): the "
+                                   "kernels made device_posting_visits_per_step of the posting_visits_per_step visits")
         if not a.no_cpu_baseline:
             wd.phase = "cpu baseline"
             out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 6.0))
