@@ -30,6 +30,21 @@ def test_config_struct_matches_header():
     assert ctypes.sizeof(_lib.Stats) == 264
 
 
+def test_python_constants_and_stats_fields_match_the_header():
+    """every APSS_FLAG_* / APSS_DOWNGRADE_* / APSS_E_* value of include/apss.h equals its mirror in apss/_lib.py, and the
+    ctypes Stats lists the header's apss_stats fields in the header's order"""
+    hdr = open(os.path.join(ROOT, "include", "apss.h")).read()
+    seen = 0
+    for name, val in re.findall(r"#define\s+APSS_((?:FLAG|DOWNGRADE|E)_[A-Z_0-9]+)\s+\(?(-?\d+)u?\)?", hdr):
+        assert getattr(_lib, name) == int(val), (name, val)
+        seen += 1
+    assert seen >= 14, seen
+    body = re.search(r"typedef struct apss_stats \{(.*?)\} apss_stats;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [m.group(1) for m in re.finditer(r"\b(?:int64_t|uint32_t|int32_t|double|float|char)\s+([a-z_0-9]+)\s*(?:\[\d+\])?\s*;", body)]
+    assert fields == [f for f, _ in _lib.Stats._fields_], (fields, [f for f, _ in _lib.Stats._fields_])
+
+
 def test_no_cpu_fallback(so):
     import torch
     if torch.cuda.is_available():
