@@ -7,6 +7,7 @@ object NativeApss {
   val FLAG_VALUE_PRUNE = 1
   val FLAG_ADMISSION = 2
   val FLAG_NORMALIZE = 4
+  val FLAG_NO_SYMMETRY = 64 // a batch that is the whole store is probed in both directions, as IndexingWorkerActor does (include/apss.h)
   /** headTerms: dense-head block of the library (0 = it decides from the term distribution, -1 = never) */
   @native def create(dim: Int, theta: Double, indexThreshold: Double, flags: Int, device: Int, headTerms: Int): Long
   @native def destroy(h: Long): Unit
