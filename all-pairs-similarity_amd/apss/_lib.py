@@ -17,8 +17,17 @@ SYMBOLS = [
     "apss_insert_and_query", "apss_self_join", "apss_result_count", "apss_fetch_results", "apss_size",
     "apss_stats_get", "apss_insert_dev", "apss_query_dev", "apss_insert_and_query_dev", "apss_clear",
     "apss_results_dev", "apss_results_copy_dev", "apss_partial_scores_dev", "apss_set_head_terms", "apss_get_head_terms", "apss_set_head_fold",
+    "apss_ext_ids_dev",
+    # the term-sharded index of one node behind one object (csrc/apss_group.hip)
+    "apss_group_create", "apss_group_destroy", "apss_group_last_error", "apss_group_set_term_cuts", "apss_group_insert",
+    "apss_group_query", "apss_group_insert_and_query", "apss_group_insert_and_query_dev", "apss_group_clear",
+    "apss_group_result_count", "apss_group_fetch_results", "apss_group_stats_get", "apss_group_member_stats",
 ]
+GROUP_FORCE_EXCHANGE, GROUP_NO_RCCL = 1, 2
+EXCHANGE_NONE, EXCHANGE_COPIES, EXCHANGE_RCCL = 0, 1, 2
+GROUP_MAX_MEMBERS = 64
 DOWNGRADE_ACC8, DOWNGRADE_HEAD = 1, 2
+SYM_RAN, SYM_FLAG, SYM_NOT_WHOLE, SYM_PATH, SYM_LONG_ROWS, SYM_ONE_TILE, SYM_CHUNK = 0, 1, 2, 3, 4, 5, 6
 
 
 class Config(C.Structure):
@@ -29,14 +38,25 @@ class Config(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rows", C.c_int64), ("nnz", C.c_int64), ("tiles", C.c_int64), ("posting_visits", C.c_int64),
+    _fields_ = [("struct_size", C.c_int32), ("symmetric", C.c_uint32), ("rows", C.c_int64), ("nnz", C.c_int64), ("tiles", C.c_int64), ("posting_visits", C.c_int64),
                 ("candidate_pairs", C.c_int64), ("result_pairs", C.c_int64), ("probe_ms", C.c_double),
                 ("build_ms", C.c_double), ("probe_launches", C.c_int64), ("hbm_bytes", C.c_int64),
                 ("filter_survivors", C.c_int64), ("rescore_ms", C.c_double),
                 ("head_terms", C.c_int64), ("head_pairs", C.c_int64), ("head_survivors", C.c_int64),
                 ("head_ms", C.c_double), ("head_flops", C.c_double), ("thin_launches", C.c_int64),
                 ("downgrades", C.c_uint32), ("head_columns", C.c_uint32), ("probe_kernel", C.c_char * 96),
-                ("device_posting_visits", C.c_int64), ("symmetric", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("device_posting_visits", C.c_int64), ("symmetric_declined", C.c_uint32), ("query_chunk", C.c_int32),
+                ("filter_tile_rows", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class GroupStats(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("n_members", C.c_int32), ("exchange", C.c_int32), ("head_terms", C.c_int32),
+                ("rows", C.c_int64), ("nnz", C.c_int64), ("posting_visits", C.c_int64), ("device_posting_visits", C.c_int64),
+                ("member_touched_pairs", C.c_int64), ("candidates_sum", C.c_int64), ("candidates_max", C.c_int64),
+                ("union_pairs", C.c_int64), ("result_pairs", C.c_int64), ("all_gather_bytes", C.c_int64),
+                ("all_reduce_bytes", C.c_int64), ("member_ms_max", C.c_double), ("probe_ms_max", C.c_double),
+                ("build_ms_max", C.c_double), ("head_ms_max", C.c_double), ("exchange_ms", C.c_double),
+                ("partial_ms_max", C.c_double), ("total_ms", C.c_double), ("term_cuts", C.c_int32 * (GROUP_MAX_MEMBERS + 1))]
 
 
 def build_sources():
@@ -52,8 +72,10 @@ def build(force=False):
     if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # two translation units (the handle: kernels + C ABI of one index; the group: term shards of one node + their exchange);
+    # RCCL is loaded at run time (dlopen), never linked
     subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-o", SO_PATH,
-                           os.path.join(CSRC, "apss_hip.hip")])
+                           os.path.join(CSRC, "apss_hip.hip"), os.path.join(CSRC, "apss_group.hip"), "-ldl", "-lpthread"])
     return SO_PATH
 
 
@@ -141,5 +163,33 @@ def lib():
     L.apss_set_head_fold.argtypes = [vp, i32]
     L.apss_get_head_terms.restype = i32
     L.apss_get_head_terms.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.apss_ext_ids_dev.restype = i32
+    L.apss_ext_ids_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.apss_group_create.restype = i32
+    L.apss_group_create.argtypes = [C.POINTER(Config), i32, vp, C.c_uint32, C.POINTER(vp)]
+    L.apss_group_destroy.restype = None
+    L.apss_group_destroy.argtypes = [vp]
+    L.apss_group_last_error.restype = C.c_char_p
+    L.apss_group_last_error.argtypes = [vp]
+    L.apss_group_set_term_cuts.restype = i32
+    L.apss_group_set_term_cuts.argtypes = [vp, vp]
+    L.apss_group_insert.restype = i32
+    L.apss_group_insert.argtypes = [vp, i64, vp, vp, vp, vp]
+    for name in ("apss_group_query", "apss_group_insert_and_query"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, i64, vp, vp, vp, vp, pi64]
+    L.apss_group_insert_and_query_dev.restype = i32
+    L.apss_group_insert_and_query_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp, pi64]
+    L.apss_group_clear.restype = i32
+    L.apss_group_clear.argtypes = [vp]
+    L.apss_group_result_count.restype = i32
+    L.apss_group_result_count.argtypes = [vp, pi64]
+    L.apss_group_fetch_results.restype = i32
+    L.apss_group_fetch_results.argtypes = [vp, i64, i64, vp, vp, vp]
+    L.apss_group_stats_get.restype = i32
+    L.apss_group_stats_get.argtypes = [vp, C.POINTER(GroupStats)]
+    L.apss_group_member_stats.restype = i32
+    L.apss_group_member_stats.argtypes = [vp, i32, C.POINTER(Stats)]
     _lib = L
     return L

@@ -120,6 +120,7 @@ class ApssIndex:
 
     def stats(self):
         st = _lib.Stats()
+        st.struct_size = C.sizeof(_lib.Stats)
         self._chk(self._L.apss_stats_get(self._h, C.byref(st)))
         d = {k: getattr(st, k) for k, _ in _lib.Stats._fields_}
         d["probe_kernel"] = d["probe_kernel"].decode()
@@ -193,3 +194,113 @@ class ApssIndex:
         assert q_row.dtype == torch.int32 and c_slot.dtype == torch.int32 and out.dtype == torch.float32
         self._chk(self._L.apss_partial_scores_dev(self._h, q_row.numel(), C.c_void_p(q_row.data_ptr()),
                                                   C.c_void_p(c_slot.data_ptr()), C.c_void_p(out.data_ptr())))
+
+
+class ApssGroup:
+    """Python face of apss_group (include/apss.h): the term-sharded index of one node -- `devices[i]` holds member i's
+    term range -- behind one object; the members' exchange (all-gather of candidate lists, all-reduce of partial scores)
+    runs below the C ABI (RCCL when every member has its own GPU, device-to-device copies when members share one).
+    Mirrors WriteWorkerActor.scala:164-183 + EntryProxyActor.scala:37-49 + IndexingWorkerActor.scala:122-137."""
+
+    def __init__(self, dim, theta, devices, flags=0, index_threshold=0.0, tile_rows=0, head_terms=0, group_flags=0,
+                 term_cuts=None, capacity_rows=0, capacity_nnz=0):
+        L = _lib.lib()
+        cfg = _lib.Config()
+        cfg.struct_size = C.sizeof(_lib.Config)
+        cfg.dim, cfg.theta, cfg.index_threshold = int(dim), float(theta), float(index_threshold)
+        cfg.flags, cfg.tile_rows, cfg.head_terms = int(flags), int(tile_rows), int(head_terms)
+        cfg.capacity_rows, cfg.capacity_nnz = int(capacity_rows), int(capacity_nnz)
+        devs = _np(devices, np.int32)
+        g = C.c_void_p()
+        rc = L.apss_group_create(C.byref(cfg), devs.size, _ptr(devs), int(group_flags), C.byref(g))
+        if rc != _lib.OK:
+            raise ApssError(rc, (L.apss_group_last_error(None) or b"").decode())
+        self._g, self._L = g, L
+        self.dim, self.theta, self.n_members = int(dim), float(theta), int(devs.size)
+        if term_cuts is not None:
+            cuts = _np(term_cuts, np.int32)
+            if cuts.size != devs.size + 1:
+                raise ValueError("term_cuts must have n_members + 1 entries")
+            self._chk(L.apss_group_set_term_cuts(self._g, _ptr(cuts)))
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._L.apss_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != _lib.OK:
+            raise ApssError(rc, (self._L.apss_group_last_error(self._g) or b"").decode())
+
+    _csr = ApssIndex._csr
+
+    def insert(self, ids, rowptr, indices, values):
+        ids, rowptr, indices, values = self._csr(ids, rowptr, indices, values)
+        self._chk(self._L.apss_group_insert(self._g, ids.size, _ptr(rowptr), _ptr(indices), _ptr(values), _ptr(ids)))
+
+    def query(self, ids, rowptr, indices, values):
+        ids, rowptr, indices, values = self._csr(ids, rowptr, indices, values)
+        n = C.c_int64(0)
+        self._chk(self._L.apss_group_query(self._g, ids.size, _ptr(rowptr), _ptr(indices), _ptr(values), _ptr(ids), C.byref(n)))
+        return self.fetch()
+
+    def insert_and_query(self, ids, rowptr, indices, values, fetch=True):
+        """the IndexData handler on every member + the exchange, IWA:123-137"""
+        ids, rowptr, indices, values = self._csr(ids, rowptr, indices, values)
+        n = C.c_int64(0)
+        self._chk(self._L.apss_group_insert_and_query(self._g, ids.size, _ptr(rowptr), _ptr(indices), _ptr(values), _ptr(ids),
+                                                      C.byref(n)))
+        return self.fetch() if fetch else n.value
+
+    def insert_and_query_dev(self, per_member):
+        """per_member: for every member (ids int64, rowptr int64, indices int32, values fp32) torch tensors on ITS device"""
+        n = nnz = None
+        tabs = [(C.c_void_p * self.n_members)() for _ in range(4)]
+        for i, (ids, rowptr, indices, values) in enumerate(per_member):
+            m, z, rp, ix, vl, ex = ApssIndex._dev(rowptr, indices, values, ids)
+            assert n in (None, m) and nnz in (None, z), "every member is handed the same batch"
+            n, nnz = m, z
+            tabs[0][i], tabs[1][i], tabs[2][i], tabs[3][i] = rp, ix, vl, ex
+        out = C.c_int64(0)
+        self._chk(self._L.apss_group_insert_and_query_dev(self._g, n, nnz, tabs[0], tabs[1], tabs[2], tabs[3], C.byref(out)))
+        return out.value
+
+    def result_count(self):
+        n = C.c_int64(0)
+        self._chk(self._L.apss_group_result_count(self._g, C.byref(n)))
+        return n.value
+
+    def fetch(self):
+        n = self.result_count()
+        q, c, s = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.float32)
+        if n:
+            self._chk(self._L.apss_group_fetch_results(self._g, 0, n, _ptr(q), _ptr(c), _ptr(s)))
+        return q, c, s
+
+    def clear(self):
+        self._chk(self._L.apss_group_clear(self._g))
+
+    def stats(self):
+        st = _lib.GroupStats()
+        st.struct_size = C.sizeof(_lib.GroupStats)
+        self._chk(self._L.apss_group_stats_get(self._g, C.byref(st)))
+        d = {k: getattr(st, k) for k, _ in _lib.GroupStats._fields_}
+        d["term_cuts"] = list(st.term_cuts[: self.n_members + 1])
+        return d
+
+    def member_stats(self, member):
+        st = _lib.Stats()
+        st.struct_size = C.sizeof(_lib.Stats)
+        self._chk(self._L.apss_group_member_stats(self._g, int(member), C.byref(st)))
+        d = {k: getattr(st, k) for k, _ in _lib.Stats._fields_}
+        d["probe_kernel"] = d["probe_kernel"].decode()
+        return d

@@ -1447,6 +1447,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.posting_visits = h->st.candidate_pairs = h->st.result_pairs = 0;
   h->st.device_posting_visits = 0;
   h->st.symmetric = 0;
+  h->st.symmetric_declined = APSS_SYM_NOT_WHOLE;
+  h->st.query_chunk = 0;
+  h->st.filter_tile_rows = 0;
   h->st.probe_ms = 0;
   h->st.probe_launches = 0;
   h->st.thin_launches = 0;
@@ -1632,8 +1635,13 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // kernels count a tile pair below the diagonal twice: both statistics are symmetric in the two tiles), and
   // device_posting_visits says what the kernels visited.
   bool tri = false;
-  if (coarse_path && !cxv.vrows && !dbg.no_sym && !(h->cfg.flags & APSS_FLAG_NO_SYMMETRY) && q_slot_base == 0 && nq == h->idx_rows &&
-      nq == h->n_rows && tail_n == 0 && ix.n_tiles > 1) {
+  uint32_t sym_declined = APSS_SYM_RAN;  // why not (apss_stats.symmetric_declined)
+  if (dbg.no_sym || (h->cfg.flags & APSS_FLAG_NO_SYMMETRY)) sym_declined = APSS_SYM_FLAG;
+  else if (!(q_slot_base == 0 && nq == h->idx_rows && nq == h->n_rows && tail_n == 0)) sym_declined = APSS_SYM_NOT_WHOLE;
+  else if (!coarse_path) sym_declined = APSS_SYM_PATH;
+  else if (cxv.vrows) sym_declined = APSS_SYM_LONG_ROWS;
+  else if (ix.n_tiles <= 1) sym_declined = APSS_SYM_ONE_TILE;
+  else {
     int64_t qc = 1;
     while (qc < a.q_chunk) qc <<= 1;
     if (qc <= ix.cb && ix.cb % qc == 0) {
@@ -1641,8 +1649,13 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       a.tri = 1;
       a.q_chunk = (int32_t)qc;
       a.n_chunks = (int32_t)ceil_div(nq, qc);
+    } else {
+      sym_declined = APSS_SYM_CHUNK;
     }
   }
+  h->st.symmetric_declined = sym_declined;
+  h->st.query_chunk = a.q_chunk;
+  h->st.filter_tile_rows = ix.cb;
   const int vrow_part = 512;
   // (the filter kernels keep their LDS in static arrays: no dynamic allocation)
   const size_t lds = coarse_path ? 0
@@ -2154,7 +2167,13 @@ int32_t apss_stats_get(apss_handle *h, apss_stats *out) {
   h->st.downgrades = h->downgrades;
   h->st.head_terms = h->head_k ? (int64_t)h->head_terms.size() : 0;  // (as they are now: a policy handle is asked after its insert)
   h->st.head_columns = (uint32_t)h->head_k;
-  *out = h->st;
+  // the caller says how large ITS apss_stats is: an older caller's shorter struct gets the fields it knows, nothing beyond
+  const int32_t caller = out->struct_size;
+  if (caller < (int32_t)(2 * sizeof(int32_t)) || caller > (1 << 16))
+    return fail(h, APSS_E_INVALID, "apss_stats.struct_size must be set to sizeof(apss_stats) before the call");
+  const int32_t n = std::min<int32_t>(caller, (int32_t)sizeof(apss_stats));
+  h->st.struct_size = n;
+  std::memcpy(out, &h->st, (size_t)n);
   return APSS_OK;
 }
 
@@ -2281,6 +2300,13 @@ int32_t apss_get_head_terms(apss_handle *h, int32_t capacity, int32_t *out_terms
   *n_terms = n;
   if (out_terms)
     for (int32_t i = 0; i < std::min(n, capacity); ++i) out_terms[i] = h->head_terms[(size_t)i];
+  return APSS_OK;
+}
+
+int32_t apss_ext_ids_dev(apss_handle *h, const int64_t **d_store_ext, const int64_t **d_query_ext) {
+  if (!h) return APSS_E_INVALID;
+  if (d_store_ext) *d_store_ext = h->n_rows > 0 ? h->ext.p : nullptr;
+  if (d_query_ext) *d_query_ext = h->res_q_ext;
   return APSS_OK;
 }
 

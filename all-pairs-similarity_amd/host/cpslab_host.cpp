@@ -210,15 +210,35 @@ GpuIndexingWorker::GpuIndexingWorker(const Config &conf, ReplyTo replyTo) : conf
   c.flags = conf.applyIndexThreshold ? APSS_FLAG_VALUE_PRUNE : 0u;
   c.device_id = conf.deviceId;
   c.tile_rows = conf.tileRows;
+  c.head_terms = conf.headTerms;
+  if (conf.devices.size() > 1 || conf.groupFlags) {
+    // the term-sharded index of the node behind one object: the reference's DataPacket fan-out to its term workers
+    // (WriteWorkerActor.scala:164-183, EntryProxyActor.scala:37-49) happens inside the library
+    std::vector<int32_t> dev(conf.devices.begin(), conf.devices.end());
+    if (dev.empty()) dev.push_back(conf.deviceId);
+    const int32_t rc = apss_group_create(&c, (int32_t)dev.size(), dev.data(), conf.groupFlags, &g_);
+    if (rc != APSS_OK) throw std::runtime_error(std::string("apss_group_create: ") + apss_group_last_error(nullptr));
+    return;
+  }
+  if (conf.devices.size() == 1) c.device_id = conf.devices[0];
   const int32_t rc = apss_create(&c, &h_);
   if (rc != APSS_OK) throw std::runtime_error(std::string("apss_create: ") + apss_last_error(nullptr));
 }
 
-GpuIndexingWorker::~GpuIndexingWorker() { apss_destroy(h_); }
+GpuIndexingWorker::~GpuIndexingWorker() {
+  if (g_) apss_group_destroy(g_);
+  else apss_destroy(h_);
+}
 
 int64_t GpuIndexingWorker::storedVectors() const {
   int64_t rows = 0;
-  apss_size(h_, &rows, nullptr);
+  if (g_) {
+    apss_group_stats st{};
+    st.struct_size = (int32_t)sizeof(st);
+    if (apss_group_stats_get(g_, &st) == APSS_OK) rows = st.rows;
+  } else {
+    apss_size(h_, &rows, nullptr);
+  }
   return rows;
 }
 
@@ -244,14 +264,21 @@ SimilarityOutput GpuIndexingWorker::handle(const IndexData &m) {
   }
   int64_t n_res = 0;
   const int64_t n = (int64_t)ids.size();
-  const int32_t rc = stop_update_index_  // IndexingWorkerActor.scala:125-133
-                         ? apss_query(h_, n, rowptr.data(), idx.data(), val.data(), ids.data(), &n_res)
-                         : apss_insert_and_query(h_, n, rowptr.data(), idx.data(), val.data(), ids.data(), &n_res);
-  if (rc != APSS_OK) throw std::runtime_error(apss_last_error(h_));
+  int32_t rc;
+  if (g_)
+    rc = stop_update_index_  // IndexingWorkerActor.scala:125-133
+             ? apss_group_query(g_, n, rowptr.data(), idx.data(), val.data(), ids.data(), &n_res)
+             : apss_group_insert_and_query(g_, n, rowptr.data(), idx.data(), val.data(), ids.data(), &n_res);
+  else
+    rc = stop_update_index_
+             ? apss_query(h_, n, rowptr.data(), idx.data(), val.data(), ids.data(), &n_res)
+             : apss_insert_and_query(h_, n, rowptr.data(), idx.data(), val.data(), ids.data(), &n_res);
+  if (rc != APSS_OK) throw std::runtime_error(g_ ? apss_group_last_error(g_) : apss_last_error(h_));
   std::vector<int64_t> q((size_t)n_res), c((size_t)n_res);
   std::vector<float> s((size_t)n_res);
-  if (n_res && apss_fetch_results(h_, 0, n_res, q.data(), c.data(), s.data()) != APSS_OK)
-    throw std::runtime_error(apss_last_error(h_));
+  if (n_res && (g_ ? apss_group_fetch_results(g_, 0, n_res, q.data(), c.data(), s.data())
+                   : apss_fetch_results(h_, 0, n_res, q.data(), c.data(), s.data())) != APSS_OK)
+    throw std::runtime_error(g_ ? apss_group_last_error(g_) : apss_last_error(h_));
   SimilarityOutput out;
   for (const auto &kv : m.vectors) out.output[kv.first];  // every query gets an entry, possibly empty (:106-107)
   for (int64_t i = 0; i < n_res; ++i) out.output[name_of_[(size_t)q[i]]][name_of_[(size_t)c[i]]] = (double)s[i];

@@ -19,6 +19,7 @@
 #include <vector>
 
 struct apss_handle;
+struct apss_group;
 
 namespace cpslab {
 
@@ -83,6 +84,11 @@ struct Config {
   bool applyIndexThreshold = false;
   int deviceId = 0;
   int tileRows = 0;
+  // cpslab.allpair.gpu.devices (GpuIndexingWorkerActor.scala): more than one entry = the term-sharded index of the node, one
+  // member per listed GPU (apss_group, include/apss.h); empty or one entry = one handle on deviceId / that device
+  std::vector<int> devices;
+  int headTerms = 0;          // cpslab.allpair.gpu.headTerms
+  unsigned groupFlags = 0;    // APSS_GROUP_* (tests: the RCCL exchange with one member)
 };
 
 // IndexingWorkerActor with vectorsStore / invertedIndex resident on the GPU.
@@ -106,6 +112,7 @@ class GpuIndexingWorker {
   Config conf_;
   ReplyTo reply_to_;
   apss_handle *h_ = nullptr;
+  apss_group *g_ = nullptr;   // set instead of h_ when conf.devices names several GPUs (or groupFlags force the exchange)
   bool stop_update_index_ = false;
   std::unordered_map<std::string, int64_t> id_of_;  // String id <-> the ABI's int64 handle
   std::vector<std::string> name_of_;

@@ -74,6 +74,34 @@ int main() {
   w2.receive(IOTicket{});
   CHECK(got2.size() == 1);  // empty buffer: no message
 
+  // the same streaming KAT through the term-sharded index of the node (cpslab.allpair.gpu.devices): two members sharing GPU 0
+  // (exchange by copies), then one member running the RCCL exchange itself (APSS_GROUP_FORCE_EXCHANGE = 1)
+  for (int variant = 0; variant < 2; ++variant) {
+    Config cg = conf;
+    if (variant == 0) cg.devices = {0, 0};
+    else { cg.devices = {0}; cg.groupFlags = 1u; }
+    std::vector<SimilarityOutput> gg;
+    GpuIndexingWorker wg(cg, [&](const SimilarityOutput &o) { gg.push_back(o); });
+    IndexData b1, b2, b3;
+    b1.vectors = {{"v1", SparseVector(4, {0, 2}, {0.6, 0.8})}, {"v3", SparseVector(4, {2}, {1.0})}};
+    b2.vectors = {{"v2", SparseVector(4, {0, 2}, {0.6, 0.8})}, {"v5", SparseVector(4, {0}, {1.0})}};
+    wg.receive(b1);
+    wg.receive(b2);
+    CHECK(gg.size() == 2 && wg.lastError().empty());
+    if (gg.size() == 2) {
+      auto &o1 = gg[0].output, &o2 = gg[1].output;
+      CHECK(o1.size() == 2 && o1["v1"].size() == 1 && near(o1["v1"]["v3"], 0.8) && near(o1["v3"]["v1"], 0.8));
+      CHECK(o2["v2"].size() == 3 && near(o2["v2"]["v1"], 1.0) && near(o2["v2"]["v3"], 0.8) && near(o2["v2"]["v5"], 0.6));
+      CHECK(o2["v5"].size() == 2 && near(o2["v5"]["v1"], 0.6) && near(o2["v5"]["v2"], 0.6));
+    }
+    CHECK(wg.storedVectors() == 4);
+    wg.receiveTimeout();
+    b3.vectors = {{"v6", SparseVector(4, {2, 3}, {0.8, 0.6})}};
+    wg.receive(b3);
+    CHECK(gg.size() == 3 && wg.storedVectors() == 4);
+    if (gg.size() == 3) CHECK(gg[2].output["v6"].size() == 3 && near(gg[2].output["v6"]["v3"], 0.8));
+  }
+
   std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: PASS\n", fails);
   return fails ? 1 : 0;
 }

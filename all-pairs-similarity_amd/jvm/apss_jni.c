@@ -47,10 +47,14 @@ JNIEXPORT jstring JNICALL Java_cpslab_gpu_NativeApss_lastError(JNIEnv *env, jcla
   return (*env)->NewStringUTF(env, apss_last_error(H(h)));
 }
 
-/* mode 0 = insert, 1 = query (frozen index), 2 = insertAndQuery; returns the number of result triples or a negative status */
-JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_submit(JNIEnv *env, jclass cls, jlong h, jint mode, jlongArray rowptr,
-                                                          jintArray indices, jdoubleArray values, jlongArray ids) {
-  (void)cls;
+#define G(x) ((apss_group *)(intptr_t)(x))
+
+/* One CSR batch copied out of the Java heap, checked against the lengths it claims, handed to `call`, freed. */
+typedef int32_t (*apss_submit_fn)(void *target, int mode, int64_t n, const int64_t *rp, const int32_t *ix, const double *vl,
+                                  const int64_t *id, int64_t *n_res);
+
+static jlong submit_csr(JNIEnv *env, void *target, apss_submit_fn call, jint mode, jlongArray rowptr, jintArray indices,
+                        jdoubleArray values, jlongArray ids) {
   const jsize n = (*env)->GetArrayLength(env, ids);
   const jsize n_rp = (*env)->GetArrayLength(env, rowptr);
   const jsize n_ix = (*env)->GetArrayLength(env, indices);
@@ -72,10 +76,7 @@ JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_submit(JNIEnv *env, jclass cl
       out = (jlong)APSS_E_INVALID;
     } else {
       int64_t n_res = 0;
-      int32_t rc;
-      if (mode == 0) rc = apss_insert(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id);
-      else if (mode == 1) rc = apss_query(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id, &n_res);
-      else rc = apss_insert_and_query(H(h), n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id, &n_res);
+      const int32_t rc = call(target, mode, n, (const int64_t *)rp, (const int32_t *)ix, vl, (const int64_t *)id, &n_res);
       out = rc == APSS_OK ? (jlong)n_res : (jlong)rc;
     }
   }
@@ -86,9 +87,10 @@ JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_submit(JNIEnv *env, jclass cl
   return out;
 }
 
-JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_fetch(JNIEnv *env, jclass cls, jlong h, jlong count, jlongArray outQ,
-                                                        jlongArray outC, jfloatArray outScore) {
-  (void)cls;
+typedef int32_t (*apss_fetch_fn)(void *target, int64_t count, int64_t *q, int64_t *c, float *s);
+
+static jint fetch_triples(JNIEnv *env, void *target, apss_fetch_fn call, jlong count, jlongArray outQ, jlongArray outC,
+                          jfloatArray outScore) {
   if (count < 0 || (*env)->GetArrayLength(env, outQ) < count || (*env)->GetArrayLength(env, outC) < count ||
       (*env)->GetArrayLength(env, outScore) < count)
     return APSS_E_INVALID;
@@ -98,7 +100,7 @@ JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_fetch(JNIEnv *env, jclass cls,
   float *s = (float *)malloc(sizeof(float) * (size_t)count);
   int32_t rc = APSS_E_NOMEM;
   if (q && c && s) {
-    rc = apss_fetch_results(H(h), 0, count, q, c, s);
+    rc = call(target, count, q, c, s);
     if (rc == APSS_OK) {
       (*env)->SetLongArrayRegion(env, outQ, 0, (jsize)count, (const jlong *)q);
       (*env)->SetLongArrayRegion(env, outC, 0, (jsize)count, (const jlong *)c);
@@ -109,6 +111,101 @@ JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_fetch(JNIEnv *env, jclass cls,
   free(c);
   free(q);
   return rc;
+}
+
+static int32_t handle_submit(void *t, int mode, int64_t n, const int64_t *rp, const int32_t *ix, const double *vl, const int64_t *id,
+                             int64_t *n_res) {
+  if (mode == 0) return apss_insert((apss_handle *)t, n, rp, ix, vl, id);
+  if (mode == 1) return apss_query((apss_handle *)t, n, rp, ix, vl, id, n_res);
+  return apss_insert_and_query((apss_handle *)t, n, rp, ix, vl, id, n_res);
+}
+
+static int32_t handle_fetch(void *t, int64_t count, int64_t *q, int64_t *c, float *s) {
+  return apss_fetch_results((apss_handle *)t, 0, count, q, c, s);
+}
+
+static int32_t group_submit(void *t, int mode, int64_t n, const int64_t *rp, const int32_t *ix, const double *vl, const int64_t *id,
+                            int64_t *n_res) {
+  if (mode == 0) return apss_group_insert((apss_group *)t, n, rp, ix, vl, id);
+  if (mode == 1) return apss_group_query((apss_group *)t, n, rp, ix, vl, id, n_res);
+  return apss_group_insert_and_query((apss_group *)t, n, rp, ix, vl, id, n_res);
+}
+
+static int32_t group_fetch(void *t, int64_t count, int64_t *q, int64_t *c, float *s) {
+  return apss_group_fetch_results((apss_group *)t, 0, count, q, c, s);
+}
+
+/* mode 0 = insert, 1 = query (frozen index), 2 = insertAndQuery; returns the number of result triples or a negative status */
+JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_submit(JNIEnv *env, jclass cls, jlong h, jint mode, jlongArray rowptr,
+                                                          jintArray indices, jdoubleArray values, jlongArray ids) {
+  (void)cls;
+  return submit_csr(env, H(h), handle_submit, mode, rowptr, indices, values, ids);
+}
+
+JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_fetch(JNIEnv *env, jclass cls, jlong h, jlong count, jlongArray outQ,
+                                                        jlongArray outC, jfloatArray outScore) {
+  (void)cls;
+  return fetch_triples(env, H(h), handle_fetch, count, outQ, outC, outScore);
+}
+
+/* ---- apss_group: the term-sharded index of one node (one member per entry of `devices`) behind one object: what the
+ * reference's DataPacket fan-out to maxShardNum x maxIndexEntryActorNum workers becomes on the GPUs of one host
+ * (WriteWorkerActor.scala:164-183, EntryProxyActor.scala:37-49); the members' exchange runs below this boundary (RCCL). */
+JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_createGroup(JNIEnv *env, jclass cls, jint dim, jdouble theta,
+                                                               jdouble indexThreshold, jint flags, jintArray devices,
+                                                               jint headTerms, jint groupFlags) {
+  (void)cls;
+  const jsize n = (*env)->GetArrayLength(env, devices);
+  if (n < 1 || n > APSS_GROUP_MAX_MEMBERS) return 0;
+  jint dev[APSS_GROUP_MAX_MEMBERS];
+  (*env)->GetIntArrayRegion(env, devices, 0, n, dev);
+  if ((*env)->ExceptionCheck(env)) return 0;
+  apss_config c = {0};
+  c.struct_size = (int32_t)sizeof(c);
+  c.dim = dim;
+  c.theta = theta;
+  c.index_threshold = indexThreshold;
+  c.flags = (uint32_t)flags;
+  c.head_terms = headTerms;
+  apss_group *g = 0;
+  return apss_group_create(&c, n, (const int32_t *)dev, (uint32_t)groupFlags, &g) == APSS_OK ? (jlong)(intptr_t)g : 0;
+}
+
+JNIEXPORT void JNICALL Java_cpslab_gpu_NativeApss_destroyGroup(JNIEnv *env, jclass cls, jlong g) {
+  (void)env; (void)cls;
+  apss_group_destroy(G(g));
+}
+
+JNIEXPORT jstring JNICALL Java_cpslab_gpu_NativeApss_groupLastError(JNIEnv *env, jclass cls, jlong g) {
+  (void)cls;
+  return (*env)->NewStringUTF(env, apss_group_last_error(G(g)));
+}
+
+JNIEXPORT jlong JNICALL Java_cpslab_gpu_NativeApss_groupSubmit(JNIEnv *env, jclass cls, jlong g, jint mode, jlongArray rowptr,
+                                                               jintArray indices, jdoubleArray values, jlongArray ids) {
+  (void)cls;
+  return submit_csr(env, G(g), group_submit, mode, rowptr, indices, values, ids);
+}
+
+JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_groupFetch(JNIEnv *env, jclass cls, jlong g, jlong count, jlongArray outQ,
+                                                             jlongArray outC, jfloatArray outScore) {
+  (void)cls;
+  return fetch_triples(env, G(g), group_fetch, count, outQ, outC, outScore);
+}
+
+/* {members, exchange (APSS_EXCHANGE_*), head terms, rows, candidates summed over the members, distinct candidates, result pairs,
+ * bytes all-gathered per member, bytes all-reduced} of the last call: what an operator logs per batch */
+JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_groupStats(JNIEnv *env, jclass cls, jlong g, jlongArray out) {
+  (void)cls;
+  if ((*env)->GetArrayLength(env, out) < 9) return APSS_E_INVALID;
+  apss_group_stats st;
+  st.struct_size = (int32_t)sizeof(st);
+  const int32_t rc = apss_group_stats_get(G(g), &st);
+  if (rc != APSS_OK) return rc;
+  const jlong v[9] = {st.n_members, st.exchange, st.head_terms, st.rows, st.candidates_sum, st.union_pairs, st.result_pairs,
+                      st.all_gather_bytes, st.all_reduce_bytes};
+  (*env)->SetLongArrayRegion(env, out, 0, 9, v);
+  return APSS_OK;
 }
 
 JNIEXPORT jint JNICALL Java_cpslab_gpu_NativeApss_setHeadTerms(JNIEnv *env, jclass cls, jlong h, jintArray terms, jint part,

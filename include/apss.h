@@ -83,6 +83,9 @@ typedef struct apss_config {
 } apss_config;
 
 typedef struct apss_stats {
+  int32_t struct_size;      /* IN: sizeof(apss_stats) as the caller compiled it -- apss_stats_get writes no more than that many
+                               bytes (the struct grows at its end from release to release); OUT: the bytes written */
+  uint32_t symmetric;       /* 1: the last call ran as a symmetric whole-store join (see APSS_FLAG_NO_SYMMETRY) */
   int64_t rows;             /* vectors in the store */
   int64_t nnz;              /* postings in the index */
   int64_t tiles;            /* candidate tiles */
@@ -108,14 +111,27 @@ typedef struct apss_stats {
                                not serve on its fast layout; each costs one full index rebuild when it happens */
   uint32_t head_columns;    /* width of a row of the dense-head block at the last call: 64 | 128 | 256 (0: none) */
   char probe_kernel[96];    /* the probe kernel instantiation the last query-type call launched, as rocprofv3 prints its name up
-                               to the template arguments' spelling, e.g. "k_probe_even<512,6,128,0,0,0>" (threads, window steps,
+                               to the template arguments' spelling, e.g. "k_probe_even<512, 6, 128, false, false, false>" (threads, window steps,
                                long-segment list, shard rule, signed, 8-bit accumulators); "" before any probe */
   int64_t device_posting_visits; /* posting visits the kernels of the last call actually made: equal to posting_visits except
                                     on a symmetric whole-store join, where posting_visits / candidate_pairs keep counting what
                                     the reference's two-directional probe visits and the device visits about half of it */
-  uint32_t symmetric;       /* 1: the last call ran as a symmetric whole-store join (see APSS_FLAG_NO_SYMMETRY) */
-  uint32_t reserved0;
+  uint32_t symmetric_declined; /* APSS_SYM_*: why the last query-type call did NOT run as a symmetric join (0 when it did) */
+  int32_t query_chunk;      /* query rows per workgroup of the last probe launch (the symmetric join needs a power of two that
+                               divides filter_tile_rows) */
+  int32_t filter_tile_rows; /* candidate rows per tile of the index rendering the last probe ran over */
+  int32_t reserved0;
 } apss_stats;
+
+/* apss_stats.symmetric_declined */
+#define APSS_SYM_RAN 0u          /* the call ran symmetrically */
+#define APSS_SYM_FLAG 1u         /* APSS_FLAG_NO_SYMMETRY (or the debug token) */
+#define APSS_SYM_NOT_WHOLE 2u    /* the query batch is not the whole indexed store (a batch onto an older store, an outside
+                                    batch, rows waiting outside the tile index) */
+#define APSS_SYM_PATH 3u         /* the call did not take the two-pass filter (theta <= 0, exact-accumulate, signed fallback) */
+#define APSS_SYM_LONG_ROWS 4u    /* a query row of more than 512 terms is cut into parts (virtual rows) */
+#define APSS_SYM_ONE_TILE 5u     /* the index has a single tile: nothing to halve */
+#define APSS_SYM_CHUNK 6u        /* the query chunk does not divide a tile (query_chunk, filter_tile_rows) */
 
 #define APSS_DOWNGRADE_ACC8 1u /* 8-bit accumulators over 65536 / 131072-row tiles given up (a long row, a large norm, an
                                   unselective byte filter): 16-bit accumulators over smaller tiles */
@@ -212,6 +228,112 @@ int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *term
 int32_t apss_set_head_fold(apss_handle *h, int32_t columns);
 /* the block's terms in block order (chosen by the library or set by the caller); *n_terms = how many there are */
 int32_t apss_get_head_terms(apss_handle *h, int32_t capacity, int32_t *out_terms, int32_t *n_terms);
+/* device views of the external ids: int64[rows] of the store, int64[query rows] of the last query batch (NULL before
+ * any query-type call / after an insert); valid until the next insert, query-type call or clear */
+int32_t apss_ext_ids_dev(apss_handle *h, const int64_t **d_store_ext, const int64_t **d_query_ext);
+
+/* =====================================================================================================================
+ * apss_group: the term-sharded index of one node -- T member shards, one per GPU -- behind ONE object.
+ *
+ * The reference shards its inverted index by term inside the server: WriteWorkerActor buckets every vector by
+ * dim % maxShardNum and flushes one DataPacket per shard (WriteWorkerActor.scala:164-183), EntryProxyActor fans a packet out
+ * to maxIndexEntryActorNum IndexingWorkerActors by dim % maxIndexEntryActorNum (EntryProxyActor.scala:37-49), and every
+ * worker handles IndexData on its own (IndexingWorkerActor.scala:122-137), re-scoring the full vectors it was sent.  A group
+ * is that fan-out and its workers on the GPUs of one node: member g owns a contiguous term RANGE (cut on the first batch,
+ * balanced by sum df^2), stores only that slice of every vector and runs the member-local phase of the join; the group
+ * combines the members' answers with the exchange the reference does not need because it replicates whole vectors:
+ *
+ *   1. every member, concurrently (one host thread per member): apss_insert_and_query_dev / apss_query_dev on its shard
+ *      handle -> CANDIDATE pairs (the shard rule above apss_partial_scores_dev);
+ *   2. all-gather of the members' candidate lists (8-B keys), sorted union on every member;
+ *   3. every member: exact partial score of every pair of the union (apss_partial_scores_dev);
+ *   4. all-reduce(SUM) of the partial scores, `>= theta` (IWA:93), compaction on member 0.
+ *
+ * Exchange (steps 2 and 4): RCCL over xGMI (ncclBroadcast-grouped all-gather, ncclAllReduce on the members' streams; librccl
+ * is loaded on first use) when every member has a GPU of its own; members that SHARE a device (tests on a one-GPU box) are
+ * combined by device-to-device copies and a summing kernel -- same lists, same order, same results.
+ * On skewed data the members share one dense-head block (apss_set_head_terms): member 0's device runs the library's policy
+ * on a sample of the first batch and every member is given the same terms; apss_config.head_terms = -1 disables it.
+ *
+ * One thread at a time inside a group (it is one actor's state); results stay in the group until the next query-type
+ * call, insert or clear.  apss_config: dim, theta, index_threshold, flags, tile_rows, head_terms and the capacity hints
+ * apply to every member; device_id, term_lo, term_hi are ignored (the group sets them).  APSS_FLAG_ADMISSION is not
+ * supported with more than one member and a dense-head block (as on a single shard handle).
+ * ===================================================================================================================== */
+typedef struct apss_group apss_group;
+
+#define APSS_GROUP_FORCE_EXCHANGE 1u /* run the exchange (steps 2-4) even for a group of ONE member, whose handle holds the whole
+                                        term space and whose answer is already final (test hook: the RCCL path on one GPU) */
+#define APSS_GROUP_NO_RCCL 2u        /* never load RCCL: combine the members with device-to-device copies (peer access or staging
+                                        through the host) even when every member has its own GPU */
+
+#define APSS_EXCHANGE_NONE 0   /* one member, its answer is final */
+#define APSS_EXCHANGE_COPIES 1 /* device-to-device copies + summing kernel (members share a device, or APSS_GROUP_NO_RCCL) */
+#define APSS_EXCHANGE_RCCL 2   /* RCCL collectives on the members' streams */
+
+#define APSS_GROUP_MAX_MEMBERS 64
+
+typedef struct apss_group_stats {
+  int32_t struct_size;        /* IN: sizeof(apss_group_stats) of the caller; OUT: bytes written (as apss_stats) */
+  int32_t n_members;
+  int32_t exchange;           /* APSS_EXCHANGE_* the last query-type call used */
+  int32_t head_terms;         /* terms in the members' shared dense-head block (0: none) */
+  int64_t rows;               /* vectors in the store (every member holds its slice of each) */
+  int64_t nnz;                /* postings over all members */
+  int64_t posting_visits;     /* sum over the members, last query-type call (reference-equivalent: see apss_stats) */
+  int64_t device_posting_visits;
+  int64_t member_touched_pairs; /* sum over the members of apss_stats.candidate_pairs (a pair sharing terms in k ranges counts k times) */
+  int64_t candidates_sum;     /* sum over the members of the candidate lists' lengths (step 1) */
+  int64_t candidates_max;     /* ... the longest list */
+  int64_t union_pairs;        /* distinct candidates (step 2) */
+  int64_t result_pairs;       /* pairs >= theta */
+  int64_t all_gather_bytes;   /* bytes every member RECEIVES in step 2: 8 x (candidates_sum - its own) at most */
+  int64_t all_reduce_bytes;   /* 4 x union_pairs: the vector of step 4 */
+  double member_ms_max;       /* wall time of step 1, slowest member (ingest + build + filter kernels + their syncs) */
+  double probe_ms_max;        /* apss_stats.probe_ms, slowest member */
+  double build_ms_max;
+  double head_ms_max;
+  double exchange_ms;         /* wall time of steps 2-4 (gather, union, partial scores, reduce, threshold) */
+  double partial_ms_max;      /* ... of which apss_partial_scores_dev, slowest member */
+  double total_ms;            /* wall time of the call */
+  int32_t term_cuts[APSS_GROUP_MAX_MEMBERS + 1]; /* member g owns terms [term_cuts[g], term_cuts[g + 1]) (head terms excepted) */
+} apss_group_stats;
+
+/* n_members >= 1 shards on the HIP devices device_ids[0 .. n_members) (a device may appear more than once) */
+int32_t apss_group_create(const apss_config *cfg, int32_t n_members, const int32_t *device_ids, uint32_t group_flags,
+                          apss_group **out);
+void apss_group_destroy(apss_group *g);
+/* message of the last failing call ("" if none); g == NULL: last apss_group_create failure */
+const char *apss_group_last_error(const apss_group *g);
+/* Name the term ranges instead of letting the first batch decide: cuts[0] = 0 < cuts[1] < .. < cuts[n_members] = dim.
+ * Before the group's first insert only (the members' handles are created with their ranges then). */
+int32_t apss_group_set_term_cuts(apss_group *g, const int32_t *cuts);
+
+/* host-pointer entry points (what the JNI shim binds): the CSR batch of apss_insert / apss_query / apss_insert_and_query,
+ * handed WHOLE to every member (each keeps its term range) */
+int32_t apss_group_insert(apss_group *g, int64_t n, const int64_t *rowptr, const int32_t *indices, const double *values,
+                          const int64_t *ext_ids);
+int32_t apss_group_query(apss_group *g, int64_t n, const int64_t *rowptr, const int32_t *indices, const double *values,
+                         const int64_t *ext_ids, int64_t *n_results);
+int32_t apss_group_insert_and_query(apss_group *g, int64_t n, const int64_t *rowptr, const int32_t *indices,
+                                    const double *values, const int64_t *ext_ids, int64_t *n_results);
+/* device-pointer entry point: member m reads the batch from d_rowptr[m], d_indices[m], d_values[m], d_ext_ids[m], resident
+ * on ITS device (members that share a device may be given the same pointers); layouts as apss_insert_and_query_dev */
+int32_t apss_group_insert_and_query_dev(apss_group *g, int64_t n, int64_t nnz, const int64_t *const *d_rowptr,
+                                        const int32_t *const *d_indices, const float *const *d_values,
+                                        const int64_t *const *d_ext_ids, int64_t *n_results);
+/* drop index and store of every member; the reservations and the LAYOUT stay -- term cuts and dense-head terms, whether named
+ * by the caller or decided from the first batch the group ever saw (they are configuration, like apss_set_head_terms on a
+ * handle: a benchmark step re-runs build + join on the same layout); a new layout needs a new group */
+int32_t apss_group_clear(apss_group *g);
+
+int32_t apss_group_result_count(const apss_group *g, int64_t *n_results);
+/* (query ext id, candidate ext id, score) of the last query-type call, as apss_fetch_results */
+int32_t apss_group_fetch_results(apss_group *g, int64_t offset, int64_t count, int64_t *out_q, int64_t *out_c,
+                                 float *out_score);
+int32_t apss_group_stats_get(apss_group *g, apss_group_stats *out);
+/* the shard handle's own statistics (out->struct_size set by the caller, as apss_stats_get) */
+int32_t apss_group_member_stats(apss_group *g, int32_t member, apss_stats *out);
 
 #ifdef __cplusplus
 }

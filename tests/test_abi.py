@@ -27,7 +27,8 @@ def test_header_symbols_are_exported(so):
 
 def test_config_struct_matches_header():
     assert ctypes.sizeof(_lib.Config) == 64
-    assert ctypes.sizeof(_lib.Stats) == 264
+    assert ctypes.sizeof(_lib.Stats) == 280
+    assert ctypes.sizeof(_lib.GroupStats) == 424
 
 
 def test_python_constants_and_stats_fields_match_the_header():
@@ -35,14 +36,29 @@ def test_python_constants_and_stats_fields_match_the_header():
     ctypes Stats lists the header's apss_stats fields in the header's order"""
     hdr = open(os.path.join(ROOT, "include", "apss.h")).read()
     seen = 0
-    for name, val in re.findall(r"#define\s+APSS_((?:FLAG|DOWNGRADE|E)_[A-Z_0-9]+)\s+\(?(-?\d+)u?\)?", hdr):
+    for name, val in re.findall(r"#define\s+APSS_((?:FLAG|DOWNGRADE|E|SYM|GROUP|EXCHANGE)_[A-Z_0-9]+)\s+\(?(-?\d+)u?\)?", hdr):
         assert getattr(_lib, name) == int(val), (name, val)
         seen += 1
-    assert seen >= 14, seen
+    assert seen >= 27, seen
     body = re.search(r"typedef struct apss_stats \{(.*?)\} apss_stats;", hdr, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = [m.group(1) for m in re.finditer(r"\b(?:int64_t|uint32_t|int32_t|double|float|char)\s+([a-z_0-9]+)\s*(?:\[\d+\])?\s*;", body)]
     assert fields == [f for f, _ in _lib.Stats._fields_], (fields, [f for f, _ in _lib.Stats._fields_])
+    body = re.search(r"typedef struct apss_group_stats \{(.*?)\} apss_group_stats;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [m.group(1) for m in re.finditer(r"\b(?:int64_t|uint32_t|int32_t|double|float|char)\s+([a-z_0-9]+)\s*(?:\[[^\]]+\])?\s*;", body)]
+    assert fields == [f for f, _ in _lib.GroupStats._fields_], (fields, [f for f, _ in _lib.GroupStats._fields_])
+
+
+def test_stats_struct_size_protects_an_older_caller(so):
+    """apss_stats / apss_group_stats grow at their end; the caller names ITS size and the library writes no further (checked
+    without a GPU on the argument validation only: a handle cannot exist here)"""
+    hdr = open(os.path.join(ROOT, "include", "apss.h")).read()
+    for name in ("apss_stats", "apss_group_stats"):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, re.S).group(1)
+        assert re.match(r"\s*int32_t struct_size;", body), name
+    src = open(os.path.join(_lib.CSRC, "apss_hip.hip")).read()
+    assert "std::min<int32_t>(caller, (int32_t)sizeof(apss_stats))" in src
 
 
 def test_no_cpu_fallback(so):
@@ -82,7 +98,7 @@ def test_every_included_header_is_in_the_staleness_list():
     """an edit to any file libapss_hip.so is compiled from must rebuild it: the #include "..." closure of apss_hip.hip is
     inside _lib.build_sources(), and the Makefile names the same files"""
     csrc = _lib.CSRC
-    seen, todo = set(), [os.path.join(csrc, "apss_hip.hip")]
+    seen, todo = set(), [os.path.join(csrc, "apss_hip.hip"), os.path.join(csrc, "apss_group.hip")]
     while todo:
         f = os.path.normpath(todo.pop())
         if f in seen:
@@ -93,5 +109,9 @@ def test_every_included_header_is_in_the_staleness_list():
     srcs = {os.path.normpath(s) for s in _lib.build_sources()}
     assert seen <= srcs, seen - srcs
     mk = open(os.path.join(csrc, "Makefile")).read()
-    rule = re.search(r"^libapss_hip\.so:(.*)$", mk, re.M).group(1).split()
+    rule = []
+    for obj in ("apss_hip.o", "apss_group.o"):
+        rule += re.search(r"^%s:(.*)$" % re.escape(obj), mk, re.M).group(1).split()
     assert {os.path.normpath(os.path.join(csrc, d)) for d in rule} == seen, (rule, seen)
+    link = re.search(r"^libapss_hip\.so:(.*)$", mk, re.M).group(1).split()
+    assert link == ["apss_hip.o", "apss_group.o"], link

@@ -20,6 +20,16 @@ def test_jni_names_match_the_scala_declarations():
     scala = open(os.path.join(JVM, "NativeApss.scala")).read()
     natives = set(re.findall(r"@native def (\w+)", scala))
     exported = set(re.findall(r"Java_cpslab_gpu_NativeApss_(\w+)\(", c))
-    assert natives == exported and natives == {"create", "destroy", "lastError", "submit", "fetch", "setHeadTerms", "setHeadFold", "headTerms"}
+    assert natives == exported and natives == {
+        "create", "destroy", "lastError", "submit", "fetch", "setHeadTerms", "setHeadFold", "headTerms",
+        "createGroup", "destroyGroup", "groupLastError", "groupSubmit", "groupFetch", "groupStats"}
     # no critical sections: the library calls block on the GPU
     assert "GetPrimitiveArrayCritical(" not in c.split("*/", 1)[1]
+
+
+def test_scala_docs_name_the_values_the_library_accepts():
+    """the fold widths in NativeApss.scala are the ones apss_set_head_fold takes (the doc once named 128 | 256)"""
+    scala = open(os.path.join(JVM, "NativeApss.scala")).read()
+    src = open(os.path.join(ROOT, "all-pairs-similarity_amd", "csrc", "apss_hip.hip")).read()
+    assert "columns != 0 && columns != 64 && columns != 128 && columns != 192" in src
+    assert "64 | 128 | 192" in scala and "128 | 256, 0 = default" not in scala
