@@ -40,7 +40,9 @@ __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + 
 
 // ---- RCCL, loaded on first use: libapss_hip.so itself does not depend on librccl (a single-GPU deployment, or a JVM without
 // RCCL on its library path, loads and runs without it).  A process that already maps an image with soname librccl.so.1
-// (PyTorch-ROCm bundles one) gets THAT image: there is never a second copy.
+// (PyTorch-ROCm bundles one) gets THAT image: there is never a second copy.  RTLD_LOCAL, always: promoting librccl and its
+// dependencies (librocm_smi64 ...) to the global scope lets a later loader of the same libraries bind to their statics and
+// destroy them twice at exit (seen with `import torch` after a group's first RCCL call: double free in rocm_smi's teardown).
 struct Rccl {
   void *lib = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
@@ -61,7 +63,7 @@ Rccl *load_rccl() {
   std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
   void *lib = nullptr;
   for (const std::string &n : names)
-    if ((lib = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+    if ((lib = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
   if (!lib) {
     // beside the HIP runtime this process runs on (PyTorch's bundle, or /opt/rocm/lib), then the loader's own search path
     Dl_info info;
@@ -75,7 +77,7 @@ Rccl *load_rccl() {
     }
     names.push_back("/opt/rocm/lib/librccl.so.1");
     for (const std::string &n : names)
-      if ((lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+      if ((lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
   }
   if (!lib) {
     r.err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");

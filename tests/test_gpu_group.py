@@ -112,7 +112,7 @@ def test_group_c3_uniform_200k(oracle):
     assert len(ref) > 1000
     assert_same_pairs(got, ref, theta, band=2e-5, tol=5e-6)
     assert st["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1]) and st["head_terms"] == 0
-    assert st["device_posting_visits"] < 0.6 * st["posting_visits"] and all(m["symmetric"] == 1 for m in ms)
+    assert st["device_posting_visits"] < 0.7 * st["posting_visits"] and all(m["symmetric"] == 1 for m in ms)
     assert st["candidates_max"] < 4 * len(ref) + 1000  # the exchange is of the order of the true pairs
     sample = 1000
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val, 0, sample))
