@@ -8,7 +8,9 @@ dim=100k, nnz=100, cosine theta=0.8" (the configuration the metric is quoted on)
 (c2 | c3 | c3z | c3z1 | c5s | c5 | c5z: apss/synth.py).
 
     python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (one process per GPU: apss/dist.py)
+    python bench.py --gpus N ...                  (typed without a launcher: starts the line above as a child, relays its line)
+    python bench.py --gpus N --engine group ...   (ONE process: apss_group, the sharded index + RCCL exchange behind the C ABI)
 
 N > 1 times BOTH layouts of SURVEY.md 8(e), K steps each, same barriers: the contract's (term-range shards across the N
 GPUs, RCCL all-gather of candidate lists + all-reduce of partial scores: WriteWorkerActor.scala:164-183 turned into
@@ -57,6 +59,11 @@ def parse():
     ap.add_argument("--deadline", type=float, default=900.0, help="seconds before the watchdog ends a stalled run (exit 3)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real run) | gloo (rehearsal: all ranks share GPU 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the baseline sample")
+    ap.add_argument("--engine", default="auto", help="N > 1 without a launcher: auto | dist = start torch.distributed.run as a child "
+                    "(one process per GPU, apss/dist.py) and relay its line; group = ONE process, the term-sharded index of the node "
+                    "behind the C ABI (apss_group: member threads + RCCL below the boundary)")
+    ap.add_argument("--share-device", action="store_true", help="--engine group rehearsal on a one-GPU box: every member on GPU 0 "
+                                                                "(exchange by device-to-device copies instead of RCCL)")
     return ap.parse_args()
 
 
@@ -204,14 +211,21 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
         filter_kernel += " (F staging waves, chunks dealt evenly over the adding waves; LDS accumulators, 4-B postings) + k_rescore"
     elif filter_kernel.startswith("k_probe_coarse"):
         filter_kernel += " (16-bit LDS accumulators, 4-B postings) + k_rescore"
+    # `value` counts what the DEVICE decided: on a symmetric whole-store join the filter meets every unordered tile pair once
+    # (device_share = device visits / reference visits, 0.517 at C3) and both directions of a survivor are re-scored exactly;
+    # the reference-equivalent count (both directions of every pair, as IndexingWorkerActor scores them) over the same wall
+    # time is `value_reference_equivalent`, and the same join with both directions probed is `value_two_directional`
+    device_share = dev_visits / visits if visits else 1.0
     out = {
-        "value": cands / sec_per_step,
+        "value": cands * device_share / sec_per_step,
+        "value_reference_equivalent": cands / sec_per_step,
+        "device_share_of_candidate_pairs": device_share,
         "ms_per_step": sec_per_step * 1e3,
         "posting_visits_per_step": visits,
         "device_posting_visits_per_step": dev_visits,
         "candidate_pairs_per_step": cands,
         "result_pairs_per_step": int(n_pairs),
-        "posting_visits_per_s": visits / sec_per_step,
+        "posting_visits_per_s": dev_visits / sec_per_step,
         "algorithmic_GBps_whole_step": alg_bytes / sec_per_step / 1e9,
         "build_ms": mean("build_ms"),
         "probe_kernel_ms": mean("probe_ms"),
@@ -274,8 +288,9 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
         out["symmetric_join"] = {
             "note": "the batch is the whole store, so (q, c) and (c, q) share terms and score: the filter kernels run the (query "
                     "tile, candidate tile) pairs on or below the diagonal, the survivors of the pairs below it are mirrored, and "
-                    "BOTH directions are re-scored exactly (same result list, same statistics: `value` counts the candidate "
-                    "pairs of the join as the reference scores them; the device made device_posting_visits_per_step visits)",
+                    "BOTH directions are re-scored exactly (same result list, same statistics).  `value` counts the candidate pairs "
+                    "the DEVICE decided (candidate_pairs_per_step x device share); value_reference_equivalent counts both directions "
+                    "of every pair as the reference scores them",
             "device_share_of_posting_visits": dev_visits / visits if visits else None,
             "two_directional": {"value": cands / (dt3 / len(per3)), "ms_per_step": dt3 / len(per3) * 1e3, "probe_kernel_ms": ps3 * 1e3,
                                 "frac": BYTES_PER_VISIT * visits / ps3 / 1e9 / HBM_PEAK_GBS if ps3 > 0 else None,
@@ -361,6 +376,11 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
         }
         visits = sj.last.get("device_posting_visits", sj.last["posting_visits"])  # (what the kernels visited: a whole-store shard join is symmetric)
         row["device_posting_visits_per_step"] = visits
+        # as at N = 1: `value` counts the candidate pairs the devices decided, the reference-equivalent count rides along
+        share = visits / sj.last["posting_visits"] if sj.last["posting_visits"] else 1.0
+        row["value_reference_equivalent"] = row["value"]
+        row["device_share_of_candidate_pairs"] = share
+        row["value"] = cands * share / sec
         sparse_roof = {"bound": "lds", "kernel": sj.last.get("probe_kernel") or "k_probe_coarse",
                        "achieved": BYTES_PER_VISIT * visits / world / (pm * 1e-3) / 1e9 if pm > 0 else None,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s (per GPU: slowest shard's kernel, 1/N of the job's 8-B posting visits)",
@@ -405,16 +425,117 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
         "value": head["value"], "ms_per_step": head["ms_per_step"],
         "posting_visits_per_step": head["posting_visits_per_step"], "candidate_pairs_per_step": cands,
         "result_pairs_per_step": head["result_pairs_per_step"],
-        "posting_visits_per_s": head["posting_visits_per_step"] / (head["ms_per_step"] * 1e-3),
+        "posting_visits_per_s": head["device_posting_visits_per_step"] / (head["ms_per_step"] * 1e-3),
         "device_posting_visits_per_step": head["device_posting_visits_per_step"],  # (all ranks; a whole-store shard join is symmetric)
         "algorithmic_GBps_whole_step": BYTES_PER_VISIT * head["device_posting_visits_per_step"] / (head["ms_per_step"] * 1e-3) / 1e9,
         "build_ms": head["build_ms_slowest_shard"], "probe_kernel_ms": head["probe_kernel_ms_slowest_shard"],
         "roofline": head["roofline"],
+        "value_reference_equivalent": head["value_reference_equivalent"],
+        "device_share_of_candidate_pairs": head["device_share_of_candidate_pairs"],
     }
     for k in ("roofline_dense_head", "roofline_sparse_filter", "head_terms", "head_kernel_ms_slowest_rank"):
         if k in head:
             out[k] = head[k]
     return out, head["grid"] + "; " + head["collectives"], extra
+
+
+def group_gpu(a, cfg, rp, idx, val, wd):
+    """N GPUs in ONE process: the term-sharded index of the node behind the C ABI (apss_group, include/apss.h) -- member i on
+    GPU i, one host thread per member, candidate all-gather + partial-score all-reduce over RCCL below the boundary.  A step =
+    apss_group_clear + apss_group_insert_and_query_dev on batches already resident in every member's HBM."""
+    import torch
+    from apss import _lib
+    from apss.engine import ApssGroup, ApssIndex
+    n, N = cfg["n"], a.gpus
+    devices = [0] * N if a.share_device else list(range(N))
+    wd.phase = "distinct pair count (device 0, untimed)"
+    dev0 = torch.device("cuda", 0)
+    d0 = (torch.arange(n, dtype=torch.int64, device=dev0), torch.from_numpy(rp).to(dev0), torch.from_numpy(idx).to(dev0),
+          torch.from_numpy(val.astype(np.float32)).to(dev0))
+    torch.cuda.synchronize()
+    ix0 = ApssIndex(cfg["dim"], cfg["theta"], device=0, tile_rows=a.tile_rows, head_terms=a.head_terms)
+    ix0.insert_and_query_dev(*d0)
+    cands = ix0.stats()["candidate_pairs"]
+    ix0.close()
+    per_member, made = [], {0: d0}
+    for d in devices:
+        if d not in made:
+            dv = torch.device("cuda", d)
+            made[d] = tuple(t.to(dv) for t in d0)
+        per_member.append(made[d])
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    wd.phase = "group: layout from the first batch (untimed), warm-up"
+    g = ApssGroup(cfg["dim"], cfg["theta"], devices, tile_rows=a.tile_rows, head_terms=a.head_terms)
+
+    def step():
+        g.clear()
+        return g.insert_and_query_dev(per_member)
+
+    for _ in range(max(1, a.warmup)):  # (the first call decides the layout: term cuts, dense-head block)
+        step()
+    wd.phase = "group: timed steps"
+    per = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        n_pairs = step()
+        per.append(g.stats())
+    dt = time.perf_counter() - t0  # (the group call returns when every member has finished: nothing is in flight)
+    st = per[-1]
+    members = [g.member_stats(i) for i in range(N)]
+    g.close()
+    sec = dt / a.steps
+    mean = lambda k: float(np.mean([s[k] for s in per]))  # noqa: E731
+    visits, dev_visits = st["posting_visits"], st["device_posting_visits"]
+    share = dev_visits / visits if visits else 1.0
+    pm = mean("probe_ms_max")
+    exch = {APSS: name for APSS, name in ((_lib.EXCHANGE_NONE, "none"), (_lib.EXCHANGE_COPIES, "device-to-device copies (members share a GPU)"),
+                                          (_lib.EXCHANGE_RCCL, "RCCL: ncclBroadcast-grouped all-gather + ncclAllReduce(SUM) on the members' streams"))}
+    body = {
+        "value": cands * share / sec, "value_reference_equivalent": cands / sec, "device_share_of_candidate_pairs": share,
+        "ms_per_step": sec * 1e3, "posting_visits_per_step": visits, "device_posting_visits_per_step": dev_visits,
+        "candidate_pairs_per_step": cands, "result_pairs_per_step": int(n_pairs),
+        "posting_visits_per_s": dev_visits / sec, "algorithmic_GBps_whole_step": BYTES_PER_VISIT * dev_visits / sec / 1e9,
+        "build_ms": mean("build_ms_max"), "probe_kernel_ms": pm,
+        "roofline": {"bound": "lds", "kernel": members[0]["probe_kernel"],
+                     "achieved": BYTES_PER_VISIT * dev_visits / N / (pm * 1e-3) / 1e9 if pm > 0 else None, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s (per GPU: slowest member's kernel, 1/N of the job's 8-B posting visits)",
+                     "frac": BYTES_PER_VISIT * dev_visits / N / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS if pm > 0 else None, "traffic": None},
+        "group": {"engine": "apss_group (csrc/apss_group.hip): one process, one host thread per member", "exchange": exch[st["exchange"]],
+                  "member_ms_slowest": mean("member_ms_max"), "exchange_ms": mean("exchange_ms"), "partial_scores_ms_slowest": mean("partial_ms_max"),
+                  "head_terms": st["head_terms"], "head_kernel_ms_slowest": mean("head_ms_max"),
+                  "candidates_per_member_sum": st["candidates_sum"], "candidates_longest_list": st["candidates_max"], "union": st["union_pairs"],
+                  "all_gather_bytes_per_member": st["all_gather_bytes"], "all_reduce_bytes": st["all_reduce_bytes"],
+                  "term_cuts": st["term_cuts"], "member_touched_pairs_sum": st["member_touched_pairs"],
+                  "devices": devices},
+    }
+    if a.share_device:
+        body["group"]["rehearsal"] = "every member on GPU 0: the members' kernels share one device, the exchange runs by copies -- not a scaling number"
+    par = "%d term-range members in one process (apss_group); per step: all-gather of candidate lists + all-reduce(SUM) of partial scores, %s" % (
+        N, "RCCL" if st["exchange"] == _lib.EXCHANGE_RCCL else "copies")
+    return body, par, {"layout": "term-range shards (the contract: BASELINE.json configs[3], SURVEY.md 8e) behind the C ABI", "backend": "rccl-in-library"}
+
+
+def relay_child(a):
+    """`python bench.py --gpus N` typed without a launcher: start torch.distributed.run as a CHILD process (before this
+    process touches the GPU), pass the arguments through, relay its one JSON line and its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [x for x in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif p.returncode == 0:
+        sys.stderr.write("[bench] the launched ranks printed no result line\n")
+        return 4
+    return p.returncode
 
 
 def main():
@@ -426,8 +547,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world == 1 and a.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    group_engine = world == 1 and a.gpus > 1 and a.engine == "group"
+    if world == 1 and a.gpus > 1 and not group_engine:
+        # typed without a launcher: the ranks are started here, as a child process, before anything touches the GPU
+        sys.exit(relay_child(a))
     wd = Watchdog(a.deadline, rank)
     if a.backend == "gloo":
         local_rank = 0  # rehearsal on a one-GPU box: every rank drives GPU 0, collectives on CPU tensors
@@ -500,7 +623,11 @@ def main():
         wd.done()
         return
 
-    if world == 1:
+    if group_engine:
+        d_arrays = None
+        torch.cuda.empty_cache()
+        body, parallelism, extra = group_gpu(a, cfg, rp, idx, val, wd)
+    elif world == 1:
         if d_arrays is None:
             d_arrays = (torch.from_numpy(rp).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(val.astype(np.float32)).to(dev))
         body, parallelism, extra = single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd)
@@ -514,10 +641,10 @@ def main():
             "metric": METRIC,
             "value": body.pop("value"),
             "unit": "scored candidate pairs/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": a.gpus if group_engine else world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": body.pop("ms_per_step"),
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong" if (world > 1 or group_engine) else "weak",
             "vs_baseline": None,
             "dtype": "u16+f32" if not body.get("head_terms") else "u16+bf16+f32",  # 16-bit fixed-point filter sums (+ bf16 MFMA head filter), fp32 exact rescoring
             "data": "synthetic",
@@ -530,19 +657,17 @@ def main():
         out.update(body)
         out.update(extra)
         sym = out.get("symmetric_join")
-        if sym:  # spelled out at the top level: what `value` counts, and the same join without the symmetry
-            out["value_counts"] = ("candidate pairs of the join as the reference scores them (both directions of every pair) per second of "
-                                   "step wall time; a whole-batch join is symmetric and the device probes each tile pair once "
-                                   "(symmetric_join; APSS_FLAG_NO_SYMMETRY = value_two_directional)")
+        out["value_counts"] = ("candidate pairs the DEVICE decided per second of step wall time: a whole-batch join is symmetric, the "
+                               "filter meets every unordered tile pair once (device share = device_posting_visits_per_step / "
+                               "posting_visits_per_step) and both directions of a survivor are re-scored exactly; "
+                               "value_reference_equivalent = both directions of every pair as the reference scores them, same wall "
+                               "time; value_two_directional = the same join with APSS_FLAG_NO_SYMMETRY, timed beside it")
+        if sym:
             out["value_two_directional"] = sym["two_directional"]["value"]
             out["ms_per_step_two_directional"] = sym["two_directional"]["ms_per_step"]
-        elif out.get("device_posting_visits_per_step", out.get("posting_visits_per_step")) != out.get("posting_visits_per_step"):
-            out["value_counts"] = ("candidate pairs of the join as the reference scores them (both directions of every pair) per second of "
-                                   "step wall time; shards that hold all rows join their batch symmetrically (DESIGN.md 5c): the "
-                                   "kernels made device_posting_visits_per_step of the posting_visits_per_step visits")
         if not a.no_cpu_baseline:
             wd.phase = "cpu baseline"
-            out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds if world == 1 else min(a.cpu_seconds, 6.0))
+            out["cpu_baseline"] = cpu_baseline(cfg, rp, idx, val, a.cpu_seconds if (world == 1 and not group_engine) else min(a.cpu_seconds, 6.0))
         print(json.dumps(out), flush=True)
     if world > 1:
         wd.phase = "shutdown"

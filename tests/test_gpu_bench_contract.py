@@ -44,7 +44,17 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 1e9  # the north-star floor, even on this reduced workload
-    assert abs(d["value"] - d["candidate_pairs_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # `value` = candidate pairs the DEVICE decided per second (a whole-batch join is symmetric: every unordered tile pair is
+    # met once); the reference-equivalent count (both directions, as IndexingWorkerActor scores them) and the two-directional
+    # sibling ride along at the top level
+    ref_eq = d["candidate_pairs_per_step"] / (d["ms_per_step"] * 1e-3)
+    assert abs(d["value_reference_equivalent"] - ref_eq) / ref_eq < 1e-6
+    share = d["device_posting_visits_per_step"] / d["posting_visits_per_step"]
+    assert 0.5 <= share <= 1.0 and abs(d["device_share_of_candidate_pairs"] - share) < 1e-12
+    assert abs(d["value"] - ref_eq * share) / d["value"] < 1e-6 and "value_counts" in d
+    assert abs(d["posting_visits_per_s"] - d["device_posting_visits_per_step"] / (d["ms_per_step"] * 1e-3)) / d["posting_visits_per_s"] < 1e-6
+    if share < 1.0:
+        assert d["value_two_directional"] > 0 and d["ms_per_step_two_directional"] > d["ms_per_step"] * 0.9
 
 
 def test_bench_skewed_workload_reports_an_mfma_roofline():
@@ -131,3 +141,38 @@ def test_bench_four_ranks_report_three_layouts():
     assert mid["grid"] == "2 term-range shards x 2 candidate ranges" and comp["grid"] == "1 term-range shards x 4 candidate ranges"
     assert mid["result_pairs_per_step"] == comp["result_pairs_per_step"] == d["result_pairs_per_step"] > 0
     assert mid["exchange"]["term_shards"] == 2 and mid["exchange"]["all_reduce_bytes"] > 0
+
+
+def test_bench_gpus_2_typed_without_a_launcher():
+    """`python bench.py --gpus 2` as typed (no torch.distributed.run around it): the ranks are started as a child process and
+    the line comes back with n_gpus = 2 and rc 0 (gloo rehearsal: both ranks drive GPU 0)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rows", "40000",
+                          "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _one_line(out)
+    for k in DRIVER_KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["exchange"]["term_shards"] == 2 and d["result_pairs_per_step"] > 0
+    assert d["value"] <= d["value_reference_equivalent"]
+
+
+def test_bench_group_engine_in_one_process():
+    """--engine group: N members of ONE apss_group (the term-sharded index behind the C ABI, exchange below the boundary) in
+    one process; on the one-GPU box the members share GPU 0 (rehearsal: exchange by copies).  Same result set as one GPU."""
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "60000", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-exact-row", "--no-two-directional-row"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = _one_line(one)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--engine", "group", "--share-device", "--rows", "60000",
+                          "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _one_line(out)
+    for k in DRIVER_KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and "apss_group" in d["config"]["parallelism"]
+    g = d["group"]
+    assert g["devices"] == [0, 0, 0, 0] and "copies" in g["exchange"] and "rehearsal" in g
+    assert len(g["term_cuts"]) == 5 and g["union"] >= d["result_pairs_per_step"] > 0 and g["all_reduce_bytes"] == 4 * g["union"]
+    assert d["result_pairs_per_step"] == d1["result_pairs_per_step"] and d["candidate_pairs_per_step"] == d1["candidate_pairs_per_step"]
+    assert d["posting_visits_per_step"] == d1["posting_visits_per_step"]
