@@ -58,6 +58,7 @@ struct DebugCfg {
   int fold_w = 0;              // fold_w=N       columns of the dense head's folded block (128 | 256)
   bool no_sym = false;         // no_sym         as APSS_FLAG_NO_SYMMETRY
   int mix = 0;                 // mix=E          ONE head block of 256 columns: E terms with a column each, the others folded into 256 - E
+  bool no_chain = false;       // no_chain       small batches take the exact pass with its own host round trips (as large ones do)
 };
 
 DebugCfg parse_debug_env() {
@@ -97,6 +98,7 @@ DebugCfg parse_debug_env() {
     else if (key == "fold_w") d.fold_w = val;
     else if (key == "mix") d.mix = val;
     else if (key == "no_sym") d.no_sym = val != 0;
+    else if (key == "no_chain") d.no_chain = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -178,8 +180,14 @@ struct apss_handle {
   const int32_t *last_q_idx = nullptr;
   const float *last_q_val = nullptr;
   int64_t last_nq = 0;
-  DevBuf<unsigned long long> counters, dbg;
+  DevBuf<unsigned long long> counters, dbg, chain_ctr;
   DevBuf<unsigned int> flagword;
+  // small messages (single vectors, batches of a few dozen: the reference's LoadGenerator sends ONE vector per message): the
+  // batch crosses PCIe as one packed copy out of pinned memory and the answer comes back the same way
+  char *pin = nullptr;             // pinned host staging, kPinBytes
+  DevBuf<char> pack;               // its device twin
+  const int64_t *up_rowptr = nullptr, *up_ext = nullptr;  // where upload() left the batch (the in_* arrays, or views into `pack`)
+  const int32_t *up_idx = nullptr;
   // dense-head block (apss_head.hpp): the KH most frequent terms live in W instead of the inverted index
   int32_t head_k = 0;                 // 0: no block
   bool head_fixed = false;            // the block's terms were set through apss_set_head_terms: no policy, kept across apss_clear
@@ -277,6 +285,8 @@ int32_t enter(apss_handle *h) {
 }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+constexpr size_t kPinBytes = 256 << 10;   // pinned staging of a small batch / a small answer ...
+constexpr size_t kPinScalars = 1024;      // ... + this much behind it for the small device-to-host reads (flags, counters)
 
 // ---- ingest: validate (+ optional normalise / admission / value prune / term-range filter) and append ----
 // Source arrays are device pointers (batch-relative rowptr).  Destination: the store (to_store) or the query
@@ -339,7 +349,9 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   // destination
   int64_t dst_row0 = to_store ? h->n_rows : 0, dst_nnz0 = to_store ? h->nnz : 0;
   int64_t kept_rows = n, kept_nnz = nnz;
-  unsigned int flags_host[4] = {0, 0, 0, 0};
+  unsigned int flags_stack[4] = {0, 0, 0, 0};
+  // (read back into pinned memory when the handle has it: a copy into pageable memory is staged by the runtime)
+  unsigned int *flags_host = h->pin ? reinterpret_cast<unsigned int *>(h->pin + kPinBytes) : flags_stack;
   if (transform) {
     APSS_TRY(ensure(h, h->s_rowdst, (size_t)n + 1));
     APSS_TRY(ensure(h, h->s_nnzdst, (size_t)n + 1));
@@ -349,7 +361,7 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
     HIPCHK(h, hipMemcpyAsync(&kept_rows, h->s_rowdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&kept_nnz, h->s_nnzdst.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   }
-  HIPCHK(h, hipMemcpyAsync(flags_host, h->flagword.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(flags_host, h->flagword.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));  // (pinned or stack)
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (flags_host[0] & 1u)
     return fail(h, APSS_E_INVALID, "malformed vector: indices must be strictly increasing and in [0, dim) "
@@ -1587,7 +1599,16 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.q_nnz_end = s_nnz_end;
   // ~2 workgroups per CU per tile in flight at once, tiles swept one after another (tile-major grid) so the
   // chip works on one tile's postings at a time and they stay in L2 / Infinity Cache
-  const int64_t want_chunks = dbg.chunks > 0 ? dbg.chunks : 1024;
+  // ... that is the whole-store join (a million queries: 1024 chunks of ~1000 rounds each).  A streamed batch has few queries:
+  // 1024 chunks would give a workgroup ONE round (B = 1024) for the price of its set-up (64 KB of accumulators cleared, the
+  // tile's descriptors fetched) -- measured on C3 streamed in batches of 1024: probe kernels 655 ms at 1024 chunks, 143 ms at
+  // 128.  So: as few chunks as still fill the chip four times over with the tiles there are, never fewer than nq / 256.
+  int64_t want_chunks = 1024;
+  if (h->idx_rows > 0) {
+    const int64_t tiles_now = std::max<int64_t>(1, ceil_div(h->idx_rows, h->use_coarse ? h->cx.cb : h->ex.cb));
+    want_chunks = std::min<int64_t>(1024, std::max<int64_t>(ceil_div(2048, tiles_now), ceil_div(nq, 256)));
+  }
+  if (dbg.chunks > 0) want_chunks = dbg.chunks;
   a.q_chunk = (int32_t)std::max<int64_t>(1, ceil_div(nq, want_chunks));
   a.n_chunks = (int32_t)ceil_div(nq, a.q_chunk);
   a.q_slot_base = q_slot_base;
@@ -1707,7 +1728,21 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     APSS_TRY(ensure(h, h->res_s, cap0, 0, true));
   }
   if (hybrid) APSS_TRY(ensure(h, h->head_ctr, 4));
+  // ---- small batches (single-vector messages, a few dozen rows): the exact pass is CHAINED behind the filter on the stream --
+  // k_rescore takes its pair count from the filter's counter on the device, k_tail_score appends to the same list -- and the
+  // call synchronises ONCE, reading all counters together (a host round trip costs as much as these kernels do)
+  constexpr int64_t kChainMaxQueries = 256;
+  const bool chain = coarse_path && !h->sharded && !hybrid && !tri && nq <= kChainMaxQueries && !dbg.no_chain;
+  const int64_t chain_tail_pairs = chain ? nq * tail_n : 0;
+  if (chain) APSS_TRY(ensure(h, h->chain_ctr, kCtrCount));
   for (int attempt = 0; attempt < 3; ++attempt) {
+    if (chain) {  // (room for everything the candidate list can hold + every (query, waiting row) pair)
+      // (sized for the longest tail there can be, once: the tail grows by a row per message)
+      const size_t fin_cap = h->res_q.cap + (size_t)(nq * std::max<int64_t>(tail_n, kTailMaxRows));
+      APSS_TRY(ensure(h, h->fin_q, fin_cap));
+      APSS_TRY(ensure(h, h->fin_c, fin_cap));
+      APSS_TRY(ensure(h, h->fin_s, fin_cap));
+    }
     a.dbg = nullptr;
     a.res_q = h->res_q.p;
     a.res_c = h->res_c.p;
@@ -1770,6 +1805,55 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    unsigned long long cc_stack[kCtrCount] = {0, 0, 0, 0, 0, 0}, c_stack[kCtrCount];
+    unsigned long long *cc = h->pin ? reinterpret_cast<unsigned long long *>(h->pin + kPinBytes + 64) : cc_stack;
+    unsigned long long *c = h->pin ? reinterpret_cast<unsigned long long *>(h->pin + kPinBytes + 128) : c_stack;
+    for (int k = 0; k < kCtrCount; ++k) cc[k] = 0;
+    if (chain) {
+      HIPCHK(h, hipMemsetAsync(h->chain_ctr.p, 0, kCtrCount * sizeof(unsigned long long), h->stream));
+      RescoreArgs r{};
+      r.n_pairs = (int64_t)a.res_cap;
+      r.n_pairs_dev = h->counters.p + kCtrResults;
+      r.q_row = h->res_q.p;
+      r.c_slot = h->res_c.p;
+      r.q_rowptr = q_rowptr;
+      r.q_idx = q_idx;
+      r.q_val = q_val;
+      r.c_rowptr = h->rowptr.p;
+      r.c_idx = h->idx.p;
+      r.c_val = h->val.p;
+      r.theta = (float)theta;
+      r.out_q = h->fin_q.p;
+      r.out_c = h->fin_c.p;
+      r.out_s = h->fin_s.p;
+      r.out_count = h->chain_ctr.p + kCtrResults;
+      // (grid for what such a batch usually passes; the kernel strides over whatever the counter holds)
+      const int64_t grid_pairs = std::min<int64_t>((int64_t)a.res_cap, 64 * nq + 4096);
+      hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(grid_pairs * kGroup, 256)), dim3(256), 0, h->stream, r);
+      if (tail_n > 0) {
+        TailArgs t{};
+        t.nq = nq;
+        t.n_tail = tail_n;
+        t.q_rowptr = q_rowptr;
+        t.q_idx = q_idx;
+        t.q_val = q_val;
+        t.q_ext = q_ext;
+        t.c_rowptr = h->rowptr.p;
+        t.c_idx = h->idx.p;
+        t.c_val = h->val.p;
+        t.c_ext = h->ext.p;
+        t.tail0 = h->idx_rows;
+        t.theta = (float)theta;
+        t.out_q = h->fin_q.p;
+        t.out_c = h->fin_c.p;
+        t.out_s = h->fin_s.p;
+        t.out_base = 0;  // (appends through the same counter as k_rescore: one list)
+        t.counters = h->chain_ctr.p;
+        hipLaunchKernelGGL(k_tail_score, dim3((unsigned)ceil_div(chain_tail_pairs * kGroup, 256)), dim3(256), 0, h->stream, t);
+      }
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(cc, h->chain_ctr.p, kCtrCount * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    }
     unsigned long long sparse_results = 0, head_c[4] = {0, 0, 0, 0};
     if (hybrid) {
       // the dense half: same candidate list, same counter
@@ -1781,8 +1865,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       HIPCHK(h, hipEventRecord(h->ev3, h->stream));
       HIPCHK(h, hipMemcpyAsync(head_c, h->head_ctr.p, sizeof(head_c), hipMemcpyDeviceToHost, h->stream));
     }
-    unsigned long long c[kCtrCount];
-    HIPCHK(h, hipMemcpyAsync(c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(c, h->counters.p, kCtrCount * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -1828,6 +1911,19 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       APSS_TRY(ensure(h, h->res_s, need, 0, true));
       continue;
     }
+    if (chain) {  // the exact pass has run already: its list is final
+      h->st.filter_survivors = (int64_t)c[kCtrResults];
+      h->n_res = (int64_t)cc[kCtrResults];
+      h->st.posting_visits += (int64_t)cc[kCtrVisits];
+      h->st.device_posting_visits += (int64_t)cc[kCtrVisits];
+      h->st.candidate_pairs += (int64_t)cc[kCtrCands];
+      h->st.result_pairs = h->n_res;
+      h->out_q = h->fin_q.p;
+      h->out_c = h->fin_c.p;
+      h->out_s = h->fin_s.p;
+      if (n_results) *n_results = h->n_res;
+      return APSS_OK;
+    }
     h->n_res = (int64_t)c[kCtrResults];
     h->out_q = h->res_q.p;
     h->out_c = h->res_c.p;
@@ -1861,11 +1957,38 @@ __global__ void k_narrow_f64(const double *in, float *out, int64_t n) {
 int32_t upload(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices, const double *values,
                const int64_t *ext_ids) {
   const int64_t nnz = n ? rowptr[n] : 0;
+  APSS_TRY(ensure(h, h->in_val, (size_t)std::max<int64_t>(nnz, 1)));
+  const size_t off_ext = (size_t)(n + 1) * sizeof(int64_t), off_val = off_ext + (size_t)n * sizeof(int64_t);
+  const size_t off_idx = off_val + (size_t)nnz * sizeof(double), bytes = off_idx + (size_t)nnz * sizeof(int32_t);
+  if (n > 0 && h->pin && bytes <= kPinBytes) {
+    // a small message: packed into pinned memory [rowptr | ext ids | values | indices] -> ONE truly asynchronous copy, no
+    // synchronisation here (the staging is the handle's own: the caller's arrays are consumed by the memcpy below, and every
+    // entry point synchronises before it returns)
+    APSS_TRY(ensure(h, h->pack, kPinBytes));
+    std::memcpy(h->pin, rowptr, off_ext);
+    std::memcpy(h->pin + off_ext, ext_ids, (size_t)n * sizeof(int64_t));
+    if (nnz) {
+      std::memcpy(h->pin + off_val, values, (size_t)nnz * sizeof(double));
+      std::memcpy(h->pin + off_idx, indices, (size_t)nnz * sizeof(int32_t));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->pack.p, h->pin, bytes, hipMemcpyHostToDevice, h->stream));
+    h->up_rowptr = reinterpret_cast<const int64_t *>(h->pack.p);
+    h->up_ext = reinterpret_cast<const int64_t *>(h->pack.p + off_ext);
+    h->up_idx = reinterpret_cast<const int32_t *>(h->pack.p + off_idx);
+    if (nnz) {
+      hipLaunchKernelGGL(k_narrow_f64, dim3((unsigned)std::min<int64_t>(2048, ceil_div(nnz, 256))), dim3(256), 0, h->stream,
+                         reinterpret_cast<const double *>(h->pack.p + off_val), h->in_val.p, nnz);
+      HIPCHK(h, hipGetLastError());
+    }
+    return APSS_OK;
+  }
   APSS_TRY(ensure(h, h->in_rowptr, (size_t)n + 1));
   APSS_TRY(ensure(h, h->in_ext, (size_t)std::max<int64_t>(n, 1)));
   APSS_TRY(ensure(h, h->in_idx, (size_t)std::max<int64_t>(nnz, 1)));
-  APSS_TRY(ensure(h, h->in_val, (size_t)std::max<int64_t>(nnz, 1)));
   APSS_TRY(ensure(h, h->in_val64, (size_t)std::max<int64_t>(nnz, 1)));
+  h->up_rowptr = h->in_rowptr.p;
+  h->up_ext = h->in_ext.p;
+  h->up_idx = h->in_idx.p;
   if (n) {
     HIPCHK(h, hipMemcpyAsync(h->in_rowptr.p, rowptr, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->in_ext.p, ext_ids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
@@ -2026,6 +2149,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
     return APSS_E_DEVICE;
   }
   h->stream = h->own_stream;
+  if (hipHostMalloc((void **)&h->pin, kPinBytes + kPinScalars, hipHostMallocDefault) != hipSuccess) h->pin = nullptr;  // (without it: the unpacked copies)
   if (cfg->capacity_rows > 0) {
     if (ensure(h, h->rowptr, (size_t)cfg->capacity_rows + 1, 0, true) != APSS_OK ||
         ensure(h, h->ext, (size_t)cfg->capacity_rows, 0, true) != APSS_OK) {
@@ -2063,7 +2187,8 @@ void apss_destroy(apss_handle *h) {
   release(h->head_pos); release(h->W);
   for (apss_handle::TailView *v : {&h->tv, &h->qtv}) { release(v->rowptr); release(v->idx); release(v->val); release(v->erow); }
   release(h->tv_cnt); release(h->tv_off); release(h->tv_sum); release(h->q_W); release(h->df); release(h->dedup_tab);
-  release(h->head_ctr); release(h->uq_q); release(h->uq_c); release(h->uq_s);
+  release(h->head_ctr); release(h->uq_q); release(h->uq_c); release(h->uq_s); release(h->pack); release(h->chain_ctr);
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -2088,7 +2213,7 @@ int32_t apss_insert(apss_handle *h, int64_t n, const int64_t *rowptr, const int3
   if (n == 0) return APSS_OK;
   APSS_TRY(upload(h, n, rowptr, indices, values, ext_ids));
   int64_t first = 0;
-  return insert_dev_impl(h, n, rowptr[n], h->in_rowptr.p, h->in_idx.p, h->in_val.p, h->in_ext.p, &first);
+  return insert_dev_impl(h, n, rowptr[n], h->up_rowptr, h->up_idx, h->in_val.p, h->up_ext, &first);
 }
 
 int32_t apss_query(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices, const double *values,
@@ -2096,7 +2221,7 @@ int32_t apss_query(apss_handle *h, int64_t n, const int64_t *rowptr, const int32
   APSS_TRY(enter(h));
   APSS_TRY(validate_host_csr(h, n, rowptr, indices, values, ext_ids));
   APSS_TRY(upload(h, n, rowptr, indices, values, ext_ids));
-  return query_dev_impl(h, n, n ? rowptr[n] : 0, h->in_rowptr.p, h->in_idx.p, h->in_val.p, h->in_ext.p, n_results);
+  return query_dev_impl(h, n, n ? rowptr[n] : 0, h->up_rowptr, h->up_idx, h->in_val.p, h->up_ext, n_results);
 }
 
 int32_t apss_insert_and_query(apss_handle *h, int64_t n, const int64_t *rowptr, const int32_t *indices,
@@ -2104,8 +2229,7 @@ int32_t apss_insert_and_query(apss_handle *h, int64_t n, const int64_t *rowptr, 
   APSS_TRY(enter(h));
   APSS_TRY(validate_host_csr(h, n, rowptr, indices, values, ext_ids));
   APSS_TRY(upload(h, n, rowptr, indices, values, ext_ids));
-  return apss_insert_and_query_dev(h, n, n ? rowptr[n] : 0, h->in_rowptr.p, h->in_idx.p, h->in_val.p, h->in_ext.p,
-                                   n_results);
+  return apss_insert_and_query_dev(h, n, n ? rowptr[n] : 0, h->up_rowptr, h->up_idx, h->in_val.p, h->up_ext, n_results);
 }
 
 int32_t apss_self_join(apss_handle *h, int64_t *n_results) {
@@ -2138,6 +2262,21 @@ int32_t apss_fetch_results(apss_handle *h, int64_t offset, int64_t count, int64_
   if (count == 0) return APSS_OK;
   if (!out_q || !out_c || !out_score) return fail(h, APSS_E_INVALID, "null output buffer");
   // map (query row, candidate slot) to external ids on the device, then copy out
+  if (h->pin && (size_t)count * 20 <= kPinBytes) {  // a small answer: one packed copy into pinned memory
+    APSS_TRY(ensure(h, h->pack, kPinBytes));
+    int64_t *pq = reinterpret_cast<int64_t *>(h->pack.p), *pc = pq + count;
+    float *ps = reinterpret_cast<float *>(pc + count);
+    hipLaunchKernelGGL(k_gather_ids, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, h->stream, h->out_q + offset, h->out_c + offset,
+                       h->res_q_ext, (const int64_t *)h->ext.p, count, pq, pc);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(ps, h->out_s + offset, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->pin, h->pack.p, (size_t)count * 20, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(out_q, h->pin, (size_t)count * sizeof(int64_t));
+    std::memcpy(out_c, h->pin + (size_t)count * sizeof(int64_t), (size_t)count * sizeof(int64_t));
+    std::memcpy(out_score, h->pin + (size_t)count * 2 * sizeof(int64_t), (size_t)count * sizeof(float));
+    return APSS_OK;
+  }
   APSS_TRY(ensure(h, h->s_rowdst, (size_t)count));
   APSS_TRY(ensure(h, h->s_nnzdst, (size_t)count));
   hipLaunchKernelGGL(k_gather_ids, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, h->stream,

@@ -2008,36 +2008,45 @@ struct RescoreArgs {
   int32_t *out_c;
   float *out_s;
   unsigned long long *out_count;
+  // chained launch (small batches: no host round trip between the filter and this pass): the number of pairs is what the
+  // filter's counter says when this kernel runs, capped at n_pairs (= the candidate list's capacity); null: n_pairs as given
+  const unsigned long long *n_pairs_dev;
 };
 
 __global__ void k_rescore(RescoreArgs a) {
-  const int64_t pair = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
   const int gl = threadIdx.x % kGroup;
-  const bool live = pair < a.n_pairs;
-  float s = 0.f;
-  int32_t qr = 0, cs = 0;
-  if (live) {
-    qr = a.q_row[pair];
-    cs = a.c_slot[pair];
-    const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
-    const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
-    for (int64_t k = qb + gl; k < qe; k += kGroup) {
-      const int32_t t = a.q_idx[k];
-      int64_t lo = cb, hi = ce;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+  const int64_t n = a.n_pairs_dev ? min((int64_t)*a.n_pairs_dev, a.n_pairs) : a.n_pairs;
+  const int64_t groups = (int64_t)gridDim.x * blockDim.x / kGroup;
+  const int sub = (threadIdx.x % kWave) / kGroup;  // pair of the wave this lane works on
+  // wave-uniform loop (a grid sized for an upper bound strides over what the counter holds; the usual launch takes one trip)
+  for (int64_t wb = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup - sub; wb < n; wb += groups) {
+    const int64_t pair = wb + sub;
+    const bool live = pair < n;
+    float s = 0.f;
+    int32_t qr = 0, cs = 0;
+    if (live) {
+      qr = a.q_row[pair];
+      cs = a.c_slot[pair];
+      const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
+      const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
+      for (int64_t k = qb + gl; k < qe; k += kGroup) {
+        const int32_t t = a.q_idx[k];
+        int64_t lo = cb, hi = ce;
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+        }
+        if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
       }
-      if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
     }
-  }
-  for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
-  const bool keep = live && gl == 0 && s >= a.theta;
-  const uint64_t o = wave_append(keep, a.out_count);
-  if (keep) {
-    a.out_q[o] = qr;
-    a.out_c[o] = cs;
-    a.out_s[o] = s;
+    for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
+    const bool keep = live && gl == 0 && s >= a.theta;
+    const uint64_t o = wave_append(keep, a.out_count);
+    if (keep) {
+      a.out_q[o] = qr;
+      a.out_c[o] = cs;
+      a.out_s[o] = s;
+    }
   }
 }
 
