@@ -59,6 +59,7 @@ struct DebugCfg {
   bool no_sym = false;         // no_sym         as APSS_FLAG_NO_SYMMETRY
   int mix = 0;                 // mix=E          ONE head block of 256 columns: E terms with a column each, the others folded into 256 - E
   bool no_chain = false;       // no_chain       small batches take the exact pass with its own host round trips (as large ones do)
+  bool no_append = false;      // no_append      a batch that lands in a partly filled tile rebuilds the whole tile (never appends to it)
 };
 
 DebugCfg parse_debug_env() {
@@ -99,6 +100,7 @@ DebugCfg parse_debug_env() {
     else if (key == "mix") d.mix = val;
     else if (key == "no_sym") d.no_sym = val != 0;
     else if (key == "no_chain") d.no_chain = val != 0;
+    else if (key == "no_append") d.no_append = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -144,6 +146,7 @@ struct apss_handle {
     DevBuf<Posting> post;
     DevBuf<uint32_t> post_c;
     DevBuf<int64_t> base, total;
+    DevBuf<uint32_t> scan_part;  // block sums of the segment-length scan (k_tile_scan_part)
     DevBuf<uint32_t> maxlen;   // [2] longest (tile, term) segment, number of long segments, over the builds since the rendering was last started from tile 0
     uint32_t max_seg = 0;      // host copies
     uint32_t long_segs = 0;
@@ -151,6 +154,7 @@ struct apss_handle {
     double round_chunks = 0.0;          // chunks an average stored row deals out per round (tile): chunkw / rows
     std::vector<int64_t> h_base;
     double build_ms = 0;
+    int64_t built_rows = 0;  // the rendering covers store rows [0, built_rows) (an append needs to start exactly there)
   };
   IndexSet ex, cx;
   bool use_coarse = false;  // build and use the coarse index (non-sharded handles without APSS_FLAG_EXACT_ACCUM)
@@ -167,6 +171,8 @@ struct apss_handle {
   DevBuf<int32_t> in_idx;
   DevBuf<float> s_inv, s_sub, in_val;
   DevBuf<double> in_val64;
+  DevBuf<uint2> app_seg;             // append build: the last tile's segment table and postings before the append
+  DevBuf<char> app_post;
   DevBuf<int32_t> vq_first, vrow_q;  // virtual-row table of the last query batch (queries of > 512 terms)
   DevBuf<int64_t> vrow_ptr, vrow_np, vrow_first;
   // results of the last query-type call
@@ -459,13 +465,126 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
   return APSS_OK;
 }
 
+void fill_build_args(apss_handle *h, apss_handle::IndexSet &ix, BuildArgs &b, bool scaled) {
+  // (a handle with a dense-head block builds from its tail view: the block's entries are not in the inverted index)
+  b.rowptr = h->head_k ? h->tv.rowptr.p : h->rowptr.p;
+  b.idx = h->head_k ? h->tv.idx.p : h->idx.p;
+  b.val = h->head_k ? h->tv.val.p : h->val.p;
+  b.cb = (int32_t)ix.cb;
+  b.dim = h->cfg.dim;
+  b.tile_seg = ix.seg.p;
+  b.seg_stride = (int64_t)h->cfg.dim;
+  b.coarse = ix.coarse ? 1 : 0;
+  b.seg_align = ix.align;
+  b.erow = h->head_k ? h->tv.erow.p : h->erow.p;
+  b.row_scale = scaled && ix.coarse ? h->sub.p : nullptr;  // shard rule: postings normalised by |x_g| / |x| (k_probe_coarse)
+  b.coarse_shift = ix.coarse && ix.cb <= 32768 ? 1 : 0;  // must agree with k_probe_coarse's SLOT2 (the 512-thread kernels)
+  b.coarse_wide = ix.coarse && ix.cb > 65536 ? 1 : 0;     // ... and with its WIDE (131072-row tiles)
+  b.tile_post_base = ix.base.p;
+  b.post = ix.post.p;
+  b.post_c = ix.post_c.p;
+}
+
+// segment lengths -> segment starts for tiles [tile0, tile0 + n): k_tile_scan_part + k_tile_scan_place
+int32_t launch_tile_scan(apss_handle *h, apss_handle::IndexSet &ix, int64_t tile0, int64_t n, uint32_t keep_len, unsigned long long *chunk_w,
+                         uint32_t count_long) {
+  const int32_t n_blk = (int32_t)ceil_div(h->cfg.dim, kScanBlock);
+  APSS_TRY(ensure(h, ix.scan_part, (size_t)(n * n_blk)));
+  const dim3 grid((unsigned)(n * n_blk));
+  hipLaunchKernelGGL(k_tile_scan_part, grid, dim3(1024), 0, h->stream, (const uint2 *)ix.seg.p, (int64_t)h->cfg.dim, h->cfg.dim, tile0, n_blk,
+                     (uint32_t)ix.align, ix.scan_part.p, ix.maxlen.p, chunk_w, count_long);
+  hipLaunchKernelGGL(k_tile_scan_place, grid, dim3(1024), 0, h->stream, ix.seg.p, (int64_t)h->cfg.dim, h->cfg.dim, tile0, n_blk, (uint32_t)ix.align,
+                     keep_len, (const uint32_t *)ix.scan_part.p, ix.total.p);
+  HIPCHK(h, hipGetLastError());
+  return APSS_OK;
+}
+
+// ---- APPEND rows [row0, row1) to tile `tile` of `ix`, which holds rows [tile * cb, row0) (k_tile_shift, apss_kernels.hpp) ----
+int32_t append_tile(apss_handle *h, apss_handle::IndexSet &ix, int64_t tile, int64_t row0, int64_t row1) {
+  const int64_t stride = (int64_t)h->cfg.dim;
+  const bool scaled = h->sharded || h->head_k > 0;
+  const size_t elt = ix.coarse ? sizeof(uint32_t) : sizeof(Posting);
+  const int64_t base = ix.h_base[(size_t)tile], old_total = ix.h_base[(size_t)tile + 1] - base;
+  uint2 *sg = ix.seg.p + tile * stride;
+  APSS_TRY(ensure(h, h->app_seg, (size_t)stride));
+  APSS_TRY(ensure(h, h->app_post, (size_t)std::max<int64_t>(old_total, 1) * elt));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->app_seg.p, sg, (size_t)stride * sizeof(uint2), hipMemcpyDeviceToDevice, h->stream));
+  if (old_total > 0)
+    HIPCHK(h, hipMemcpyAsync(h->app_post.p, ix.coarse ? (const void *)(ix.post_c.p + base) : (const void *)(ix.post.p + base),
+                             (size_t)old_total * elt, hipMemcpyDeviceToDevice, h->stream));
+  BuildArgs b{};
+  fill_build_args(h, ix, b, scaled);
+  b.row0 = row0;
+  b.row1 = row1;
+  const int threads = 256;
+  const int64_t blocks = ceil_div((row1 - row0) * kWave, threads);
+  hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);  // lengths: old + new
+  APSS_TRY(launch_tile_scan(h, ix, tile, 1, 0u, nullptr, 0u));
+  HIPCHK(h, hipGetLastError());
+  int64_t new_total = 0;
+  uint32_t seg_stats[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(&new_total, ix.total.p + tile, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(seg_stats, ix.maxlen.p, sizeof(seg_stats), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  ix.max_seg = seg_stats[0];
+  ix.h_base[(size_t)tile + 1] = base + new_total;
+  ix.post_used = base + new_total;
+  if (ix.coarse) APSS_TRY(ensure(h, ix.post_c, (size_t)ix.post_used + 64, (size_t)base));
+  else APSS_TRY(ensure(h, ix.post, (size_t)ix.post_used + 64, (size_t)base));
+  if (ix.coarse)  // the probe reads a zero word as "no posting": clear the tile's region (padding between segments)
+    HIPCHK(h, hipMemsetAsync(ix.post_c.p + base, 0, (size_t)(new_total + 64) * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMemcpyAsync(ix.base.p + tile + 1, ix.h_base.data() + tile + 1, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  ShiftArgs sa{};
+  sa.seg_old = h->app_seg.p;
+  sa.seg_new = sg;
+  sa.old_c = ix.coarse ? reinterpret_cast<const uint32_t *>(h->app_post.p) : nullptr;
+  sa.old_x = ix.coarse ? nullptr : reinterpret_cast<const Posting *>(h->app_post.p);
+  sa.new_c = ix.coarse ? ix.post_c.p + base : nullptr;
+  sa.new_x = ix.coarse ? nullptr : ix.post.p + base;
+  sa.dim = h->cfg.dim;
+  hipLaunchKernelGGL(k_tile_shift, dim3((unsigned)ceil_div(stride * kGroup, 256)), dim3(256), 0, h->stream, sa);
+  fill_build_args(h, ix, b, scaled);  // (the posting array may have moved)
+  b.row0 = row0;
+  b.row1 = row1;
+  hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
+  if (scaled) {
+    DevBuf<float> &tmin = ix.coarse ? h->tile_min_c : h->tile_min;
+    hipLaunchKernelGGL(k_tile_min_sub, dim3(1), dim3(1024), 0, h->stream, (const float *)h->sub.p, h->idx_rows, (int32_t)ix.cb, tmin.p, tile);
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));  // (the host vector the tile base was copied from lives on; the event gives the build its time)
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  ix.build_ms = ms;
+  return APSS_OK;
+}
+
 // ---- index build for rows [row0, n_rows): rebuild every tile of `ix` that contains one of them ----
 int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   const int64_t cb = ix.cb;
-  const int64_t tile0 = row0 / cb;
+  int64_t tile0 = row0 / cb;
   const int64_t n_tiles = ceil_div(h->idx_rows, cb);
   const int64_t stride = (int64_t)h->cfg.dim;
+  double appended_ms = 0.0;
+  if (row0 % cb != 0 && ix.built_rows == row0 && ix.n_tiles == tile0 + 1 && (int64_t)ix.h_base.size() == tile0 + 2 &&
+      !h->dbgcfg.no_append && !h->dbgcfg.bank_order) {
+    // the batch lands in the last, partly filled tile of an up-to-date rendering: append to it, build the tiles beyond as ever
+    DevBuf<float> &tmin_a = ix.coarse ? h->tile_min_c : h->tile_min;
+    if (h->sharded || h->head_k > 0) APSS_TRY(ensure(h, tmin_a, (size_t)n_tiles, (size_t)tile0 + 1));
+    APSS_TRY(ensure(h, ix.total, (size_t)n_tiles, (size_t)tile0 + 1));
+    APSS_TRY(append_tile(h, ix, tile0, row0, std::min<int64_t>(h->idx_rows, (tile0 + 1) * cb)));
+    appended_ms = ix.build_ms;
+    ++tile0;
+    row0 = tile0 * cb;
+    if (h->idx_rows <= row0) {
+      ix.built_rows = h->idx_rows;
+      return APSS_OK;
+    }
+  }
   ix.n_tiles = n_tiles;
+  ix.built_rows = h->idx_rows;
   if (n_tiles == tile0) return APSS_OK;
   APSS_TRY(ensure(h, ix.seg, (size_t)(n_tiles * stride), (size_t)(tile0 * stride)));
   APSS_TRY(ensure(h, ix.base, (size_t)n_tiles + 1, (size_t)tile0 + 1));
@@ -491,30 +610,16 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   if (!lds_build)
     HIPCHK(h, hipMemsetAsync(ix.seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
   BuildArgs b{};
-  // (a handle with a dense-head block builds from its tail view: the block's entries are not in the inverted index)
-  b.rowptr = h->head_k ? h->tv.rowptr.p : h->rowptr.p;
-  b.idx = h->head_k ? h->tv.idx.p : h->idx.p;
-  b.val = h->head_k ? h->tv.val.p : h->val.p;
+  fill_build_args(h, ix, b, scaled);
   b.row0 = r0;
   b.row1 = h->idx_rows;
-  b.cb = (int32_t)cb;
-  b.dim = h->cfg.dim;
-  b.tile_seg = ix.seg.p;
-  b.seg_stride = stride;
-  b.coarse = ix.coarse ? 1 : 0;
-  b.seg_align = ix.align;
-  b.erow = h->head_k ? h->tv.erow.p : h->erow.p;
-  b.row_scale = scaled && ix.coarse ? h->sub.p : nullptr;  // shard rule: postings normalised by |x_g| / |x| (k_probe_coarse)
-  b.coarse_shift = ix.coarse && ix.cb <= 32768 ? 1 : 0;  // must agree with k_probe_coarse's SLOT2 (the 512-thread kernels)
-  b.coarse_wide = ix.coarse && ix.cb > 65536 ? 1 : 0;     // ... and with its WIDE (131072-row tiles)
   const int threads = 256;
   const int64_t blocks = ceil_div((h->idx_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   const dim3 lds_grid((unsigned)((n_tiles - tile0) * n_ranges));
   if (lds_build) hipLaunchKernelGGL(k_tile_hist_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
   else hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
-  hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)(n_tiles - tile0)), dim3(1024), 0, h->stream, ix.seg.p, stride, h->cfg.dim,
-                     tile0, ix.total.p, (uint32_t)ix.align, lds_build ? 1u : 0u, ix.maxlen.p, tile0 == 0 ? ix.chunkw.p : nullptr);
+  APSS_TRY(launch_tile_scan(h, ix, tile0, n_tiles - tile0, lds_build ? 1u : 0u, tile0 == 0 ? ix.chunkw.p : nullptr, 1u));
   HIPCHK(h, hipGetLastError());
   // padded posting counts -> tile bases (host prefix sum: a handful of values), then reserve the posting array
   std::vector<int64_t> tot((size_t)(n_tiles - tile0));
@@ -553,7 +658,7 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   HIPCHK(h, hipEventSynchronize(h->ev1));
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  ix.build_ms = ms;
+  ix.build_ms = ms + appended_ms;
   return APSS_OK;
 }
 
@@ -1602,11 +1707,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // ... that is the whole-store join (a million queries: 1024 chunks of ~1000 rounds each).  A streamed batch has few queries:
   // 1024 chunks would give a workgroup ONE round (B = 1024) for the price of its set-up (64 KB of accumulators cleared, the
   // tile's descriptors fetched) -- measured on C3 streamed in batches of 1024: probe kernels 655 ms at 1024 chunks, 143 ms at
-  // 128.  So: as few chunks as still fill the chip four times over with the tiles there are, never fewer than nq / 256.
+  // 128.  So: as few chunks as still fill the chip eight times over with the tiles there are, never fewer than nq / 256.
   int64_t want_chunks = 1024;
   if (h->idx_rows > 0) {
     const int64_t tiles_now = std::max<int64_t>(1, ceil_div(h->idx_rows, h->use_coarse ? h->cx.cb : h->ex.cb));
-    want_chunks = std::min<int64_t>(1024, std::max<int64_t>(ceil_div(2048, tiles_now), ceil_div(nq, 256)));
+    // (eight workgroups per resident slot: with four, the last, partly filled wave of workgroups cost a fifth of the launch)
+    want_chunks = std::min<int64_t>(1024, std::max<int64_t>(ceil_div(4096, tiles_now), ceil_div(nq, 256)));
   }
   if (dbg.chunks > 0) want_chunks = dbg.chunks;
   a.q_chunk = (int32_t)std::max<int64_t>(1, ceil_div(nq, want_chunks));
@@ -1728,10 +1834,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     APSS_TRY(ensure(h, h->res_s, cap0, 0, true));
   }
   if (hybrid) APSS_TRY(ensure(h, h->head_ctr, 4));
-  // ---- small batches (single-vector messages, a few dozen rows): the exact pass is CHAINED behind the filter on the stream --
+  // ---- streamed batches (single-vector messages up to a few tens of thousands of rows): the exact pass is CHAINED behind the filter on the stream --
   // k_rescore takes its pair count from the filter's counter on the device, k_tail_score appends to the same list -- and the
   // call synchronises ONCE, reading all counters together (a host round trip costs as much as these kernels do)
-  constexpr int64_t kChainMaxQueries = 256;
+  constexpr int64_t kChainMaxQueries = 65536;
   const bool chain = coarse_path && !h->sharded && !hybrid && !tri && nq <= kChainMaxQueries && !dbg.no_chain;
   const int64_t chain_tail_pairs = chain ? nq * tail_n : 0;
   if (chain) APSS_TRY(ensure(h, h->chain_ctr, kCtrCount));
@@ -2178,7 +2284,7 @@ void apss_destroy(apss_handle *h) {
   (void)hipSetDevice(h->dev);
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   release(h->rowptr); release(h->ext); release(h->idx); release(h->erow); release(h->val); release(h->sub);
-  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); release(s->maxlen); release(s->chunkw); }
+  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { release(s->seg); release(s->post); release(s->post_c); release(s->base); release(s->total); release(s->maxlen); release(s->chunkw); release(s->scan_part); }
   release(h->tile_min); release(h->tile_min_c); release(h->fin_q); release(h->fin_c); release(h->fin_s);
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst); release(h->scan_tmp);
@@ -2187,7 +2293,7 @@ void apss_destroy(apss_handle *h) {
   release(h->head_pos); release(h->W);
   for (apss_handle::TailView *v : {&h->tv, &h->qtv}) { release(v->rowptr); release(v->idx); release(v->val); release(v->erow); }
   release(h->tv_cnt); release(h->tv_off); release(h->tv_sum); release(h->q_W); release(h->df); release(h->dedup_tab);
-  release(h->head_ctr); release(h->uq_q); release(h->uq_c); release(h->uq_s); release(h->pack); release(h->chain_ctr);
+  release(h->head_ctr); release(h->uq_q); release(h->uq_c); release(h->uq_s); release(h->pack); release(h->chain_ctr); release(h->app_seg); release(h->app_post);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -2357,7 +2463,7 @@ int32_t apss_clear(apss_handle *h) {
   h->idx_rows = 0;
   h->nnz = 0;
   h->n_tiles = 0;
-  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { s->n_tiles = 0; s->post_used = 0; s->h_base.clear(); }
+  for (apss_handle::IndexSet *s : {&h->ex, &h->cx}) { s->n_tiles = 0; s->post_used = 0; s->h_base.clear(); s->built_rows = 0; }
   h->ex_built_rows = 0;
   h->n_res = -1;
   h->res_q_ext = nullptr;

@@ -364,40 +364,33 @@ __global__ void k_tile_hist(BuildArgs a) {
   }
 }
 
-// one workgroup per tile: exclusive scan of the aligned lengths; tile_total[tile] = postings incl. padding
-__global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0,
-                                                    int64_t *tile_total, uint32_t align, uint32_t keep_len, uint32_t *max_len,
-                                                    unsigned long long *chunk_w) {
-  // one workgroup per tile walks the tile's dim entries in blocks of kScanBlock, four CONSECUTIVE entries per thread (a
-  // strided stream per thread took 4.2 ms per build at dim = 2^20, 16 tiles)
+// Exclusive scan of a tile's aligned segment lengths -> segment starts; tile_total[tile] = postings incl. padding.  Two
+// launches over (tile, block of kScanBlock terms) workgroups: k_tile_scan_part leaves every block's sum (and the build's
+// statistics), k_tile_scan_place adds up the sums of the blocks before its own and writes the starts.  (One workgroup per
+// tile walking its dim entries block after block took 85 us at dim = 100k whatever the number of tiles -- 25 dependent
+// trips -- which a streamed batch paid on every append to the last tile; a block per workgroup is one trip.)
+__global__ __launch_bounds__(1024) void k_tile_scan_part(const uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0,
+                                                         int32_t n_blk, uint32_t align, uint32_t *part, uint32_t *max_len,
+                                                         unsigned long long *chunk_w, uint32_t count_long) {
   __shared__ uint32_t wave_tot[17];
-  uint2 *sg = tile_seg + (tile0 + blockIdx.x) * seg_stride;
+  const int64_t tile = tile0 + blockIdx.x / n_blk;
+  const int32_t blk = (int32_t)(blockIdx.x % n_blk);
+  const uint2 *sg = tile_seg + tile * seg_stride;
   const int tid = threadIdx.x;
-  uint32_t carry = 0, longest = 0, n_long = 0;
+  const int32_t i0 = blk * kScanBlock + tid * 4;
+  uint32_t s = 0, longest = 0, n_long = 0;
   unsigned long long cw = 0;  // sum over the tile's short segments of length x 16-posting chunks
-  for (int32_t base = 0; base < dim; base += kScanBlock) {
-    const int32_t i0 = base + tid * 4;
-    uint32_t len[4], s = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      len[k] = i0 + k < dim ? sg[i0 + k].y : 0u;
-      s += (len[k] + align - 1) / align * align;
-      longest = max(longest, len[k]);
-      n_long += len[k] > 256u ? 1u : 0u;  // (kLongLenW: what the probe kernels sweep as a long segment)
-      cw += len[k] <= 256u ? (unsigned long long)len[k] * ((len[k] + 15u) / 16u) : 0ull;
-    }
-    uint32_t total;
-    uint32_t run = carry + block_excl_scan_1024<uint32_t>(s, wave_tot, &total);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // (the atomic scatter rebuilds .y as its cursor, the LDS scatter never touches it)
-      if (i0 + k < dim) sg[i0 + k] = make_uint2(run, keep_len ? len[k] : 0u);
-      run += (len[k] + align - 1) / align * align;
-    }
-    carry += total;
-    __syncthreads();  // (wave_tot is reused by the next block)
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t len = i0 + k < dim ? sg[i0 + k].y : 0u;
+    s += (len + align - 1) / align * align;
+    longest = max(longest, len);
+    n_long += len > 256u ? 1u : 0u;  // (kLongLenW: what the probe kernels sweep as a long segment)
+    cw += len <= 256u ? (unsigned long long)len * ((len + 15u) / 16u) : 0ull;
   }
-  if (tid == 0) tile_total[tile0 + blockIdx.x] = carry;
+  uint32_t total;
+  (void)block_excl_scan_1024<uint32_t>(s, wave_tot, &total);
+  if (tid == 0) part[blockIdx.x] = total;
   // the longest (tile, term) segment of the build: tells the probe whether its long-segment machinery is needed at all
   for (int o = kWave / 2; o; o >>= 1) {
     longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
@@ -405,13 +398,47 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint2 *tile_seg, int64_t seg
   }
   if (max_len && (tid % kWave) == 0 && longest) {
     atomicMax(max_len, longest);
-    if (n_long) atomicAdd(max_len + 1, n_long);  // [1]: long segments over all tiles of the build
+    if (n_long && count_long) atomicAdd(max_len + 1, n_long);  // [1]: long segments over all tiles of the build (an appended-to tile was counted before)
   }
   // A row of the tile holds term t with probability len_t / rows, and a query holding t meets ceil(len_t / 16) chunks of this
   // tile: sum_t len_t * ceil(len_t / 16) / rows = the chunks an average round (a query distributed like the tile's rows) deals
   // out, whatever the term distribution -- what the probe sizes its register window from
   for (int o = kWave / 2; o; o >>= 1) cw += __shfl_xor(cw, o);
   if (chunk_w && (tid % kWave) == 0 && cw) atomicAdd(chunk_w, cw);
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan_place(uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0, int32_t n_blk,
+                                                          uint32_t align, uint32_t keep_len, const uint32_t *part, int64_t *tile_total) {
+  __shared__ uint32_t wave_tot[17];
+  __shared__ uint32_t before;
+  const int64_t tile = tile0 + blockIdx.x / n_blk;
+  const int32_t blk = (int32_t)(blockIdx.x % n_blk);
+  uint2 *sg = tile_seg + tile * seg_stride;
+  const int tid = threadIdx.x;
+  // the sums of this tile's blocks before this one
+  uint32_t mine = 0u;
+  for (int32_t j = tid; j < blk; j += 1024) mine += part[(blockIdx.x / n_blk) * n_blk + j];
+  uint32_t tot_before;
+  (void)block_excl_scan_1024<uint32_t>(mine, wave_tot, &tot_before);
+  if (tid == 0) before = tot_before;
+  __syncthreads();  // (wave_tot is reused below)
+  const uint32_t carry = before;
+  const int32_t i0 = blk * kScanBlock + tid * 4;
+  uint32_t len[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    len[k] = i0 + k < dim ? sg[i0 + k].y : 0u;
+    s += (len[k] + align - 1) / align * align;
+  }
+  uint32_t total;
+  uint32_t run = carry + block_excl_scan_1024<uint32_t>(s, wave_tot, &total);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // (the atomic scatter rebuilds .y as its cursor, the LDS scatter never touches it)
+    if (i0 + k < dim) sg[i0 + k] = make_uint2(run, keep_len ? len[k] : 0u);
+    run += (len[k] + align - 1) / align * align;
+  }
+  if (blk == n_blk - 1 && tid == 0) tile_total[tile] = (int64_t)carry + (int64_t)total;
 }
 
 __global__ void k_tile_scatter(BuildArgs a) {
@@ -440,6 +467,35 @@ __global__ void k_tile_scatter(BuildArgs a) {
       a.post[pbase + pos] = p;
     }
   }
+}
+
+// APPEND build (a streamed batch lands in the last, partly filled tile: IndexingWorkerActor.scala:61-71 appends to its posting
+// lists): the new rows' terms are counted ON TOP of the tile's segment lengths (k_tile_hist over the new rows only), the scan
+// gives every segment its new start -- a segment only ever grows, the ones behind it move right --, this kernel moves the
+// tile's old postings from a scratch copy to their new places and leaves every cursor behind them, and k_tile_scatter places
+// the new rows' postings after them.  Work: the new rows + one pass over the tile's postings, instead of recounting and
+// re-scattering every row of the tile with two global atomics each.  16 lanes per term.
+struct ShiftArgs {
+  const uint2 *seg_old;   // [dim] {start, length} before the append (scratch copy)
+  uint2 *seg_new;         // [dim] {new start, 0} from k_tile_scan; .y becomes the old length (the scatter's cursor)
+  const uint32_t *old_c;  // the tile's old postings (scratch copy, offsets relative to the tile), coarse ...
+  const Posting *old_x;   // ... or exact
+  uint32_t *new_c;        // the tile's region in the posting array
+  Posting *new_x;
+  int32_t dim;
+};
+__global__ void k_tile_shift(ShiftArgs a) {
+  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  if (t >= a.dim) return;
+  const uint2 o = a.seg_old[t];
+  const uint32_t n0 = a.seg_new[t].x;
+  if (a.old_c) {
+    for (uint32_t i = gl; i < o.y; i += kGroup) a.new_c[n0 + i] = a.old_c[o.x + i];
+  } else {
+    for (uint32_t i = gl; i < o.y; i += kGroup) a.new_x[n0 + i] = a.old_x[o.x + i];
+  }
+  if (gl == 0) a.seg_new[t].y = o.y;
 }
 
 // ---------------------------------------------------------------------------------------------------------
