@@ -53,6 +53,20 @@ namespace apss {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 apss_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float apss_f32x16;
+typedef __attribute__((ext_vector_type(4))) int apss_i32x4;     // 16 int8 weights: one fragment of v_mfma_i32_32x32x32_i8
+typedef __attribute__((ext_vector_type(16))) int apss_i32x16;
+
+// ---- INT8 rendering of W (round 4).  The block is a FILTER for non-negative weights, so its rows may be rounded UP:
+//     u_c = ceil(w_c * S)  (S = 127 / the largest row norm the handle has seen when the block is first packed; 0 stays 0)
+// and  sum_k u_q[k] u_c[k] >= S^2 w_q . w_c  holds EXACTLY (integer products, int32 accumulation: no rounding bound at all),
+// so the test  acc >= floor(S^2 (theta - slack))  loses no pair the exact head test passes.  What it passes in excess: every
+// NON-ZERO element is over-estimated by less than one unit of 1/S, i.e. a pair's dot by < (sum of q over the shared columns
+// + sum of c over them) / S + shared / S^2 -- ~0.03 for a chance pair of 60-term rows sharing ~14 columns, against a
+// threshold of 0.9.  v_mfma_i32_32x32x32_i8 multiplies twice the K of the bf16 form in the same cycles (MI355X_MICROARCH.md,
+// matrix cores) and a row is 256 B instead of 512 B: half the MFMAs, half the tile stream, half the W panel per candidate.
+// Same 16-B chunk layout (a chunk holds 16 columns instead of 8), same LDS-DMA copy, same fragment reads: A and B take their
+// 16 bytes from the same chunk of their rows, so whatever order the instruction sums the 32 columns of a k-step in, column k
+// of the query meets column k of the candidate.
 
 constexpr int kHeadQBlock = 512;   // query slots per workgroup (8 waves x 64)
 constexpr int kHeadCTile = 64;     // candidate rows per LDS tile
@@ -84,6 +98,10 @@ __global__ void k_df_sample(const int64_t *rowptr, const int32_t *idx, int64_t n
 __host__ __device__ __forceinline__ int64_t head_chunk_off(int64_t row, int chunk, int kh) {
   return (((row >> 6) * (kh / 8) + chunk) * kHeadCTile + (row & 63)) * 8;
 }
+// BYTE offset of (row, 16-B chunk) in a tiled W whose rows are `cpr` chunks wide (bf16: kh / 8 chunks, int8: kh / 16)
+__host__ __device__ __forceinline__ int64_t head_chunk_byte_off(int64_t row, int chunk, int cpr) {
+  return (((row >> 6) * cpr + chunk) * kHeadCTile + (row & 63)) * 16;
+}
 constexpr int kHeadBlock = 256;      // columns per block of a two-block head
 constexpr int kHeadMaxBlocks = 2;    // (the two-block experiment form: 256 columns + a block of folded columns with its own norm)
 constexpr int kHeadMaxFold = 127;    // heads of up to 256 * 128 = 32768 terms
@@ -105,6 +123,9 @@ struct HeadPackArgs {
   float prune_above;       // an entry counts iff value * row_inv > prune_above (APSS_FLAG_VALUE_PRUNE; -inf: every entry)
   int32_t part, n_parts;   // head_nonempty counts the rows of the W tiles t % n_parts == part only (n_parts <= 1: every row)
   int32_t fold_from;       // columns >= fold_from are FOLDED (several terms add into them); below: one term per column
+  float i8_scale;          // > 0: the INT8 rendering -- element = ceil(w * i8_scale), one byte per column (W is then a byte array
+                           //   of kh-byte rows); 0: bf16
+  unsigned int *overflow;  // |= 1 when an element would exceed 127 (the handle then falls back to bf16 for good)
 };
 
 // one wave per W row, 8 rows (one 128-B line per chunk) per workgroup; the workgroup covers W rows [8 g, 8 g + 8)
@@ -153,8 +174,15 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
       if (hp >= 0 && v > a.prune_above) {
         // (block 0: a column belongs to one term, a plain store; block 1: the terms of a column ADD -- |x_{H_2}| above is the
         // norm of the entries themselves, not of the folded row)
+        // a FOLDED column holds the L2 norm of its terms (squares add here, the root is taken at write-out): by Cauchy-Schwarz
+        // per column  sum_{t in col} q_t c_t <= sqrt(sum q_t^2) sqrt(sum c_t^2), an upper bound of the column's share of the
+        // dot product like the plain sum round 3 used, but a TIGHTER one (sqrt(a^2 + b^2) <= a + b), and it keeps the row's norm:
+        // |c~| = |c_H|, so no element of w_c exceeds |c| -- which is what lets the INT8 rendering fix its scale from the row norms
         if (hp < a.fold_from) rowbuf[wv][hp] = v * scale[0];
-        else atomicAdd(&rowbuf[wv][hp], v * (hp < kHeadBlock ? scale[0] : scale[1]));
+        else {
+          const float x = v * (hp < kHeadBlock ? scale[0] : scale[1]);
+          atomicAdd(&rowbuf[wv][hp], x * x);
+        }
       }
     }
     if (lane == 0) {
@@ -164,6 +192,43 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
     }
   }
   __syncthreads();
+  for (int u = threadIdx.x; u < 8 * a.kh; u += blockDim.x) {  // folded columns: sum of squares -> L2 norm
+    const int j = u / a.kh, col = u % a.kh;
+    if (col >= a.fold_from) rowbuf[j][col] = sqrtf(rowbuf[j][col]);
+  }
+  __syncthreads();
+  if (a.i8_scale > 0.f) {
+    // INT8: 16 columns per 16-B chunk, rounded UP (a sound filter for the non-negative weights the block is built from)
+    const int cpr8 = a.kh / 16;
+    bool ovf = false;
+    for (int u = threadIdx.x; u < cpr8 * 8; u += blockDim.x) {
+      const int c = u >> 3, j = u & 7;
+      const int64_t w = g0 + j;
+      if (w >= a.w_row0 && w < a.w_pad) {
+        const float *f = &rowbuf[j][c * 16];
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t word = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const float x = f[4 * e + b];
+            int q = x > 0.f ? (int)ceilf(x * a.i8_scale) : 0;
+            if (q > 127) {
+              ovf = true;
+              q = 127;
+            }
+            word |= (uint32_t)q << (8 * b);
+          }
+          o[e] = word;
+        }
+        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(a.W) + head_chunk_byte_off(w, c, cpr8)) = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    if (ovf && a.overflow) atomicOr(a.overflow, 1u);
+    if (threadIdx.x == 0 && nz && a.head_nonempty) atomicAdd(a.head_nonempty, nz);
+    return;
+  }
   // write-out: unit u = (chunk c, row j of the group): 8 rows x 16 B = one 128-B line per chunk
   const int cpr = a.kh / 8;
   for (int u = threadIdx.x; u < cpr * 8; u += blockDim.x) {
@@ -180,6 +245,28 @@ __global__ __launch_bounds__(512) void k_head_pack(HeadPackArgs a) {
     }
   }
   if (threadIdx.x == 0 && nz && a.head_nonempty) atomicAdd(a.head_nonempty, nz);
+}
+
+// INT8 rendering: a row with a larger norm than any before needs a smaller scale S' for the WHOLE block (one threshold for
+// every pair).  The rows already packed are re-quantised in place: u' = ceil(u * S' / S) >= w S' still holds (u >= w S), so
+// the filter stays sound without the original rows (a term shard no longer has them); num / den = S' / S as a fraction of
+// 16-bit integers rounded UP.
+__global__ void k_head_rescale(unsigned char *W, int64_t n_bytes, uint32_t num, uint32_t den) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n_bytes; i += (int64_t)gridDim.x * blockDim.x * 16) {
+    uint4 v = *reinterpret_cast<const uint4 *>(W + i);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t o = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint32_t u = (w[e] >> (8 * b)) & 0xffu;
+        o |= ((u * num + den - 1) / den) << (8 * b);
+      }
+      w[e] = o;
+    }
+    *reinterpret_cast<uint4 *>(W + i) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
 }
 
 // TAIL VIEW of a CSR batch: the same rows without the entries the dense block holds -- what the inverted index is built
@@ -283,6 +370,8 @@ struct HeadGemmArgs {
   int64_t qblock0;      // first query block's first slot (a multiple of 512)
   const int64_t *q_ext, *c_ext;
   float thr;
+  int32_t thr_i;        // INT8 rendering: the threshold in units of 1 / S^2 ...
+  float inv_s2;         // ... and 1 / S^2 (a reported filter score = acc * inv_s2)
   int32_t *res_q, *res_c;
   float *res_s;
   uint64_t res_cap;
@@ -291,14 +380,40 @@ struct HeadGemmArgs {
   unsigned long long *clk;         // diagnostic kernel of the microbenchmark only: per workgroup {shader cycles, 100-MHz ticks}
 };
 
-template <int KH, bool COUNT = true, int NBUF = 3, int NW = 8>
+// the two renderings behind one kernel body: fragment and accumulator types, the MFMA, the threshold
+template <bool I8> struct HeadMma;
+template <> struct HeadMma<false> {
+  using frag = apss_bf16x8;
+  using acc = apss_f32x16;
+  using elem = float;
+  static __device__ __forceinline__ acc mma(const frag &a, const frag &b, const acc &c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ elem thr(const HeadGemmArgs &a) { return a.thr; }
+  static __device__ __forceinline__ float score(const HeadGemmArgs &, elem v) { return v; }
+  static __device__ __forceinline__ elem vmax(elem x, elem y) { return fmaxf(x, y); }
+};
+template <> struct HeadMma<true> {
+  using frag = apss_i32x4;
+  using acc = apss_i32x16;
+  using elem = int;
+  static __device__ __forceinline__ acc mma(const frag &a, const frag &b, const acc &c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ elem thr(const HeadGemmArgs &a) { return a.thr_i; }
+  static __device__ __forceinline__ float score(const HeadGemmArgs &a, elem v) { return (float)v * a.inv_s2; }
+  static __device__ __forceinline__ elem vmax(elem x, elem y) { return max(x, y); }
+};
+
+template <int KH, bool COUNT = true, int NBUF = 3, int NW = 8, bool I8 = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) {
+  using MM = HeadMma<I8>;
+  using frag_t = typename MM::frag;
+  using acc_t = typename MM::acc;
+  using elem_t = typename MM::elem;
   constexpr bool PIPE3 = NBUF >= 3;           // NBUF tile buffers in LDS: 2 = barrier at the tile boundary, >= 3 = barrier in mid-tile
   constexpr int QB = 64 * NW;                 // query slots per workgroup (kHeadQBlock in the library; 256 in an experiment of the microbenchmark)
-  constexpr int KS = KH / 16;                 // k-steps of the 32x32x16 MFMA
+  constexpr int ROWB = I8 ? KH : KH * 2;      // bytes per row
+  constexpr int KS = ROWB / 32;               // k-steps: two 16-B chunks each (32x32x16 bf16 / 32x32x32 int8)
   constexpr int SPK = 16 / KS;                // epilogue scan steps (2 accumulators each) per k-step of the other half
-  static_assert(SPK * KS == 16, "KH is 64, 128 or 256");
-  constexpr int ROWB = KH * 2;                // bytes per row
+  static_assert(SPK * KS == 16, "a row is 128, 256 or 512 bytes");
+  constexpr int CPR = ROWB / 16;              // 16-B chunks per row of this block
   constexpr int SUB = 1;                      // 64-row sub-tiles per LDS tile (32-KB tiles at KH < 256, SUB = 256 / KH, measured
   constexpr int CT = kHeadCTile * SUB;        //   slower: narrow blocks are bound by the epilogue, not by the barrier)
   constexpr int NB = CT / 32;                 // 32-candidate column blocks per tile
@@ -309,7 +424,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   constexpr int PF = 2;                       // B fragments requested ahead of the MFMAs that use them
   static_assert(PIECES % NW == 0, "every wave copies the same number of pieces");
   __shared__ __attribute__((aligned(1024))) unsigned char ldsb[NBUF * TILEB];
-  __shared__ float scratch[NW * 16 * kWave];  // reporting path only: one 32 x 32 accumulator block per wave
+  __shared__ elem_t scratch[NW * 16 * kWave];  // reporting path only: one 32 x 32 accumulator block per wave
 
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid / kWave), ln = tid % kWave;
@@ -331,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
 
   // ---- A fragments: lane (r, hh) of block m holds W[slot][16 kk + 8 hh .. + 8) = chunk 2 kk + hh of its row; the 32
   // lanes of a half read 32 consecutive rows of one chunk: 512 contiguous bytes ----
-  apss_bf16x8 af[2][KS];
+  frag_t af[2][KS];
   const int64_t wslot0 = B0 + 64 * wv;  // a multiple of 64: the wave's 64 slots are one tile of Wq
   bool wave_live = false;
 #pragma unroll
@@ -340,13 +455,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
     const int64_t row = s - qs0;
     const bool ok = row >= 0 && row < a.nq && s < a.wq_rows;
     wave_live |= ok;
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq) + ((ok ? wslot0 : 0) / kHeadCTile) * (int64_t)(a.kt / 8 * kHeadCTile) +
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.Wq) + ((ok ? wslot0 : 0) / kHeadCTile) * (int64_t)(a.kt * (I8 ? 1 : 2) / 16 * kHeadCTile) +
                        (int64_t)a.chunk0 * kHeadCTile + 32 * m + r;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (ok) v = src[(2 * kk + hh) * kHeadCTile];
-      af[m][kk] = __builtin_bit_cast(apss_bf16x8, v);
+      af[m][kk] = __builtin_bit_cast(frag_t, v);
     }
   }
   wave_live = __any(wave_live);  // a wave without a query row copies tiles but computes nothing
@@ -354,7 +469,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   // ---- tile copy by LDS-DMA: a tile is TILEB contiguous bytes in HBM and lands in LDS as it is; wave w moves the
   // 1-KiB pieces (= chunks) w * PPW .. , lane l the 16 bytes of row l ----
   auto copy_tile = [&](const int t, const int buf) {
-    const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * ((int64_t)kHeadCTile * a.kt * 2) +
+    const unsigned char *tsrc = reinterpret_cast<const unsigned char *>(a.Wc) + (int64_t)t * ((int64_t)kHeadCTile * a.kt * (I8 ? 1 : 2)) +
                                 (int64_t)a.chunk0 * (kHeadCTile * 16) + ln * 16;
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
@@ -368,7 +483,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   const uint32_t rd_lane = (uint32_t)(hh * 1024 + r * 16);
 
   unsigned long long n_pos = 0;  // positive elements seen by this lane
-  float *const sc = scratch + wv * (16 * kWave);
+  elem_t *const sc = scratch + wv * (16 * kWave);
+  const elem_t thr = MM::thr(a);
 
   // ---- the epilogue of one 64 x 32 half (column block n of a tile): nothing of D is stored.  `scan` folds two of its
   // 32 accumulators per call into the running maximum and the count of positive elements; it is called between the
@@ -376,26 +492,26 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   // strictly below a stored query block stands for (q, c) and, when c is a query of the batch too, for (c, q)) and,
   // when some element reached the threshold, report.
   struct Half {
-    float mx;
+    elem_t mx;
     uint32_t pos;
   };
-  auto scan = [&](Half &hf, const apss_f32x16 (&ac)[2], const int step) {  // step 0..15: elements 2 step, 2 step + 1 of 32
+  auto scan = [&](Half &hf, const acc_t (&ac)[2], const int step) {  // step 0..15: elements 2 step, 2 step + 1 of 32
 #ifdef APSS_GEMM_NOEPI  // (microbenchmark experiment only: the tile stream without its epilogue; results are garbage)
     if (step != 0) return;
 #endif
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = 2 * step + j;
-      const float v = ac[e >> 4][e & 15];
-      hf.mx = fmaxf(hf.mx, v);
-      if (COUNT) hf.pos += v > 0.f ? 1u : 0u;
+      const elem_t v = ac[e >> 4][e & 15];
+      hf.mx = MM::vmax(hf.mx, v);
+      if (COUNT) hf.pos += v > (elem_t)0 ? 1u : 0u;
     }
   };
-  auto finish = [&](Half &hf, const apss_f32x16 (&ac)[2], const int64_t cb_row0) {  // cb_row0: the half's first candidate row
+  auto finish = [&](Half &hf, const acc_t (&ac)[2], const int64_t cb_row0) {  // cb_row0: the half's first candidate row
     const bool below = stored && cb_row0 + 32 <= B0;
     const int64_t c = cb_row0 + r;
     n_pos += (below && c >= qs0) ? 2u * hf.pos : hf.pos;
-    if (__any(hf.mx >= a.thr)) {
+    if (__any(hf.mx >= thr)) {
       // rare (a tile holding a near-duplicate, or the block's own diagonal): the accumulators go through a wave-private
       // LDS scratch one 32 x 32 block at a time, so that the reporting loop is a real loop
       const int64_t cext = c < a.n_rows ? a.c_ext[c] : 0;
@@ -405,29 +521,29 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
         for (int i = 0; i < 16; ++i) sc[i * kWave + ln] = ac[m][i];
 #pragma unroll 1
         for (int i = 0; i < 16; ++i) {
-          const float v = sc[i * kWave + ln];
-          if (!__any(v >= a.thr)) continue;
+          const elem_t v = sc[i * kWave + ln];
+          if (!__any(v >= thr)) continue;
           const int64_t s = wslot0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
           const int64_t qrow = s - qs0;
-          bool ok = v >= a.thr && qrow >= 0 && qrow < a.nq && c < a.n_rows;
+          bool ok = v >= thr && qrow >= 0 && qrow < a.nq && c < a.n_rows;
           if (ok) ok = a.q_ext[qrow] != cext;  // self-exclusion by external id (IWA:91)
           const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
           if (ok && o < a.res_cap) {
             a.res_q[o] = (int32_t)qrow;
             a.res_c[o] = (int32_t)c;
-            a.res_s[o] = v;  // filter score; k_rescore replaces it
+            a.res_s[o] = MM::score(a, v);  // filter score; k_rescore replaces it
           }
           const bool ok2 = ok && below && c >= qs0;  // the mirrored pair: c as the query, q's slot as the candidate
           const uint64_t o2 = wave_append(ok2, &a.counters[kCtrResults]);
           if (ok2 && o2 < a.res_cap) {
             a.res_q[o2] = (int32_t)(c - qs0);
             a.res_c[o2] = (int32_t)s;
-            a.res_s[o2] = v;
+            a.res_s[o2] = MM::score(a, v);
           }
         }
       }
     }
-    hf.mx = 0.f;
+    hf.mx = (elem_t)0;
     hf.pos = 0;
   };
   // the 32 MFMAs of one half: D[64 slots][32 candidates of column block n] over the whole K.  The B fragments come
@@ -435,23 +551,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   // `between(kk)` runs after the two MFMAs of every k-step
   auto ldfrag = [&](const unsigned char *tb, const int n, const int kk) {
     // column block n of the LDS tile: 64-row sub-tile n / 2 (SUBB bytes each), rows 32 (n % 2) .. of it
-    return __builtin_bit_cast(apss_bf16x8, *reinterpret_cast<const uint4 *>(tb + rd_lane + kk * 2048 + (n >> 1) * SUBB + (n & 1) * 512));
+    return __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4 *>(tb + rd_lane + kk * 2048 + (n >> 1) * SUBB + (n & 1) * 512));
   };
-  auto mma_half = [&](apss_f32x16 (&ac)[2], const unsigned char *tb, const int n, auto &&between) {
-    apss_bf16x8 bf[PF];
+  auto mma_half = [&](acc_t (&ac)[2], const unsigned char *tb, const int n, auto &&between) {
+    frag_t bf[PF];
 #pragma unroll
     for (int j = 0; j < PF && j < KS; ++j) bf[j] = ldfrag(tb, n, j);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const apss_bf16x8 b = bf[kk % PF];
+      const frag_t b = bf[kk % PF];
       if (kk + PF < KS) bf[kk % PF] = ldfrag(tb, n, kk + PF);
       if (kk == 0) {
-        const apss_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][kk], b, zero, 0, 0, 0);
-        ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][kk], b, zero, 0, 0, 0);
+        const acc_t zero = {};
+        ac[0] = MM::mma(af[0][kk], b, zero);
+        ac[1] = MM::mma(af[1][kk], b, zero);
       } else {
-        ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][kk], b, ac[0], 0, 0, 0);
-        ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][kk], b, ac[1], 0, 0, 0);
+        ac[0] = MM::mma(af[0][kk], b, ac[0]);
+        ac[1] = MM::mma(af[1][kk], b, ac[1]);
       }
       between(kk);
     }
@@ -460,8 +576,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
   // Software pipeline by halves, no second accumulator set: the 32-candidate column blocks of a tile alternate between
   // two accumulator pairs; while the matrix cores work on block b the vector unit scans block b - 1 (the last block of
   // tile t - 1 when b = 0).
-  apss_f32x16 acc0[2], acc1[2];
-  Half h0{0.f, 0u}, h1{0.f, 0u};
+  acc_t acc0[2], acc1[2];
+  Half h0{(elem_t)0, 0u}, h1{(elem_t)0, 0u};
   int64_t pend = -1;  // first candidate row of the column block whose scan is pending in acc1 / h1 (-1: none)
   if constexpr (PIPE3) {
     // THREE tile buffers and the workgroup barrier in the MIDDLE of a tile.  With the barrier at the tile boundary every
@@ -473,20 +589,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
     // requested during tile t's last MFMAs (a rolling prefetch queue across halves and tiles), and the barrier a wave meets
     // in mid-tile finds the fragments of the MFMAs behind it already in registers.  That barrier says "tile t + 1 has
     // landed for everyone, and everyone is past tile t - 1"; the copy of tile t + 2 into tile t - 1's buffer follows it.
-    apss_bf16x8 bq[PF];
-    auto mma_run = [&](apss_f32x16 (&ac)[2], const unsigned char *tb, const int n, const unsigned char *tb_next, const int n_next,
+    frag_t bq[PF];
+    auto mma_run = [&](acc_t (&ac)[2], const unsigned char *tb, const int n, const unsigned char *tb_next, const int n_next,
                        auto &&between) {
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        const apss_bf16x8 b = bq[kk % PF];
+        const frag_t b = bq[kk % PF];
         bq[kk % PF] = kk + PF < KS ? ldfrag(tb, n, kk + PF) : ldfrag(tb_next, n_next, kk + PF - KS);
         if (kk == 0) {
-          const apss_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][kk], b, zero, 0, 0, 0);
-          ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][kk], b, zero, 0, 0, 0);
+          const acc_t zero = {};
+          ac[0] = MM::mma(af[0][kk], b, zero);
+          ac[1] = MM::mma(af[1][kk], b, zero);
         } else {
-          ac[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][kk], b, ac[0], 0, 0, 0);
-          ac[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][kk], b, ac[1], 0, 0, 0);
+          ac[0] = MM::mma(af[0][kk], b, ac[0]);
+          ac[1] = MM::mma(af[1][kk], b, ac[1]);
         }
         between(kk);
       }
@@ -602,6 +718,8 @@ struct HeadGemvArgs {
   uint64_t res_cap;
   unsigned long long *counters;
   unsigned long long *head_pairs;
+  int32_t i8;             // W is the INT8 rendering: sums are in units of 1 / S^2 (exact in fp32: < 2^24), thr is given in those units
+  float inv_s2;           // ... and a reported score = sum * inv_s2
 };
 
 constexpr int kGemvQ = 8;  // queries per pass over W
@@ -611,7 +729,8 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
   __shared__ unsigned long long npos;
   const int tid = threadIdx.x, ln = tid % kWave;
   const int64_t qs0 = a.q_slot_base >= 0 ? a.q_slot_base : 0;
-  const int cpr = a.kh / 8;
+  const int cpr = a.i8 ? a.kh / 16 : a.kh / 8;       // 16-B chunks of the block this launch multiplies
+  const int cpr_row = a.i8 ? a.kt / 16 : a.kt / 8;   // ... of a whole W row
   const int64_t n_tiles = (a.n_rows + kHeadCTile - 1) / kHeadCTile;
   if (tid == 0) npos = 0;
   unsigned long long my_pos = 0;
@@ -620,8 +739,13 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
     __syncthreads();
     for (int i = tid; i < nqq * a.kh; i += blockDim.x) {
       const int qq = i / a.kh, k = i % a.kh;
-      const uint16_t b = a.Wq[head_chunk_off(qs0 + q0 + qq, a.chunk0 + (k >> 3), a.kt) + (k & 7)];
-      qv[qq][k] = __uint_as_float((uint32_t)b << 16);
+      if (a.i8) {
+        const unsigned char *wq = reinterpret_cast<const unsigned char *>(a.Wq);
+        qv[qq][k] = (float)wq[head_chunk_byte_off(qs0 + q0 + qq, a.chunk0 + (k >> 4), cpr_row) + (k & 15)];
+      } else {
+        const uint16_t b = a.Wq[head_chunk_off(qs0 + q0 + qq, a.chunk0 + (k >> 3), a.kt) + (k & 7)];
+        qv[qq][k] = __uint_as_float((uint32_t)b << 16);
+      }
     }
     __syncthreads();
     for (int64_t tl = (int64_t)blockIdx.x * 4 + tid / kWave; a.part + tl * max(a.n_parts, 1) < n_tiles; tl += (int64_t)gridDim.x * 4) {
@@ -630,10 +754,23 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
       float s[kGemvQ];
 #pragma unroll
       for (int qq = 0; qq < kGemvQ; ++qq) s[qq] = 0.f;
-      const uint4 *tp = reinterpret_cast<const uint4 *>(a.Wc) + t * (int64_t)(a.kt / 8 * kHeadCTile) + (int64_t)a.chunk0 * kHeadCTile + ln;
+      const uint4 *tp = reinterpret_cast<const uint4 *>(a.Wc) + t * (int64_t)(cpr_row * kHeadCTile) + (int64_t)a.chunk0 * kHeadCTile + ln;
       for (int ch = 0; ch < cpr; ++ch) {
         const uint4 v = tp[ch * kHeadCTile];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (a.i8) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const float x = (float)((w[e] >> (8 * b)) & 0xffu);
+#pragma unroll
+              for (int qq = 0; qq < kGemvQ; ++qq)
+                if (qq < nqq) s[qq] += x * qv[qq][ch * 16 + 4 * e + b];
+            }
+          }
+          continue;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
@@ -653,7 +790,7 @@ __global__ __launch_bounds__(256) void k_head_gemv(const HeadGemvArgs a) {
         if (ok && o < a.res_cap) {
           a.res_q[o] = q0 + qq;
           a.res_c[o] = (int32_t)c;
-          a.res_s[o] = s[qq];
+          a.res_s[o] = a.i8 ? s[qq] * a.inv_s2 : s[qq];
         }
       }
     }

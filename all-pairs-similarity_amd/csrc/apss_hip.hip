@@ -60,6 +60,7 @@ struct DebugCfg {
   int mix = 0;                 // mix=E          ONE head block of 256 columns: E terms with a column each, the others folded into 256 - E
   bool no_chain = false;       // no_chain       small batches take the exact pass with its own host round trips (as large ones do)
   bool no_append = false;      // no_append      a batch that lands in a partly filled tile rebuilds the whole tile (never appends to it)
+  bool head_bf16 = false;      // head_bf16      the dense-head block keeps bf16 rows (v_mfma_f32_32x32x16_bf16), never the INT8 rendering
 };
 
 DebugCfg parse_debug_env() {
@@ -101,6 +102,7 @@ DebugCfg parse_debug_env() {
     else if (key == "no_sym") d.no_sym = val != 0;
     else if (key == "no_chain") d.no_chain = val != 0;
     else if (key == "no_append") d.no_append = val != 0;
+    else if (key == "head_bf16") d.head_bf16 = val != 0;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -221,7 +223,11 @@ struct apss_handle {
   TailView tv, qtv;                   // of the store rows [0, idx_rows); of the staged (outside) query batch
   DevBuf<int64_t> tv_cnt, tv_off;
   DevBuf<unsigned int> tv_sum;
-  DevBuf<uint16_t> W, q_W;            // [rows x head_k] bf16 rows of the store / of a staged query batch
+  DevBuf<uint16_t> W, q_W;            // [rows x head_k] rows of the store / of a staged query batch: bf16, or INT8 in the first half
+                                      // of the same reservation (head_i8: one byte per column, rounded up; apss_head.hpp)
+  bool head_i8 = false;               // the block's rows are the INT8 rendering (decided when the block's first row is packed)
+  float head_s = 0.f;                 // the INT8 scale S (units per 1.0): 127 / the largest row norm so far (head_fit_scale)
+  DevBuf<unsigned int> head_ovf;      // [1] set by k_head_pack if an element ever exceeded 127 (cannot happen: checked, an error)
   DevBuf<uint32_t> df;
   DevBuf<unsigned long long> dedup_tab, head_ctr;
   DevBuf<int32_t> uq_q, uq_c;         // candidate list after k_pair_dedup
@@ -313,6 +319,10 @@ int32_t scan_i64(apss_handle *h, const int64_t *in, int64_t *out, int64_t n) {
   HIPCHK(h, hipGetLastError());
   return APSS_OK;
 }
+
+int32_t head_setup_rendering(apss_handle *h);
+int32_t head_fit_scale(apss_handle *h, double norm2, unsigned char *W, int64_t packed_bytes);
+inline void head_pack_rendering(const apss_handle *h, HeadPackArgs &p);
 
 int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_idx,
                const float *d_val, const int64_t *d_ext, bool to_store, int64_t *n_out, int64_t *nnz_out) {
@@ -431,7 +441,11 @@ int32_t ingest(apss_handle *h, int64_t n, int64_t nnz, const int64_t *d_rowptr, 
     APSS_TRY(ensure(h, o_W, (size_t)(w_pad * kh), (size_t)(ceil_div(dst_row0, kHeadCTile) * kHeadCTile * kh)));
     APSS_TRY(ensure(h, h->head_ctr, 4));
     HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
+    if (to_store && dst_row0 == 0) APSS_TRY(head_setup_rendering(h));
+    APSS_TRY(head_fit_scale(h, to_store ? (double)h->store_max_norm2 : std::max((double)h->store_max_norm2, (double)h->q_max_norm2),
+                            reinterpret_cast<unsigned char *>(h->W.p), ceil_div(to_store ? dst_row0 : h->n_rows, kHeadCTile) * kHeadCTile * kh));
     HeadPackArgs p{};
+    head_pack_rendering(h, p);
     p.rowptr = d_rowptr;
     p.idx = d_idx;
     p.val = d_val;
@@ -690,8 +704,9 @@ constexpr int64_t kTailMaxBatch = 256;   // a batch larger than this extends the
 constexpr int64_t kTailMaxPairs = 1 << 22;  // (queries x tail rows) a probe scores directly; beyond it the tail is folded in first
 constexpr int32_t kHeadMaxTerms = kHeadBlock * (1 + kHeadMaxFold);   // 256 terms with a column each + 256 columns of kHeadMaxFold terms
 // width of a W row holding n_terms head terms: one block of 64 | 128 | 256 columns, or 256 + a folded block of fold_w columns
-inline int32_t head_width(int32_t n_terms, int32_t fold_w, int32_t exact = kHeadBlock) {
-  return n_terms <= 64 ? 64 : (n_terms <= 128 ? 128 : (n_terms <= 256 ? 256 : exact + fold_w));
+inline int32_t head_width(int32_t n_terms, int32_t fold_w, int32_t exact = kHeadBlock, bool i8 = false) {
+  // (INT8 rendering: a 64-column row would be 64 bytes, less than a 1-KiB DMA piece per wave and tile: 128 columns at least)
+  return n_terms <= 64 ? (i8 ? 128 : 64) : (n_terms <= 128 ? 128 : (n_terms <= 256 ? 256 : exact + fold_w));
 }
 // column of the i-th head term (most frequent first): the first `exact` get a column each, the others fold into fold_w columns
 inline int32_t head_column(int32_t i, int32_t fold_w, int32_t exact = kHeadBlock) { return i < exact ? i : exact + (i - exact) % fold_w; }
@@ -710,6 +725,45 @@ constexpr double kHeadSurvivorCost = 2.5e-9;  // seconds per element the dense f
 inline bool head_allowed(const apss_handle *h) {
   return h->use_coarse && (!h->sharded || h->head_fixed) && (h->cfg.head_terms >= 0 || h->head_fixed) && h->cfg.theta > 0.0 &&
          !h->head_blocked && h->nonneg;
+}
+
+// Which rendering the block's rows take.  INT8 (rounded up: a sound filter for the non-negative weights a block needs anyway)
+// for a single block of 128 | 256 columns; bf16 for the two-block experiment forms and on request (APSS_DEBUG=head_bf16).
+inline bool head_wants_i8(const apss_handle *h) {
+  return !h->dbgcfg.head_bf16 && !(h->dbgcfg.fold_w == 128 || h->dbgcfg.fold_w == 256);
+}
+// (re)decide the rendering for a block of width head_k whose FIRST row is about to be packed
+int32_t head_setup_rendering(apss_handle *h) {
+  h->head_i8 = h->head_k > 0 && h->head_k <= kHeadBlock && head_wants_i8(h);
+  h->head_s = 0.f;
+  APSS_TRY(ensure(h, h->head_ovf, 4));
+  HIPCHK(h, hipMemsetAsync(h->head_ovf.p, 0, 4 * sizeof(unsigned int), h->stream));
+  return APSS_OK;
+}
+// INT8 scale S (units per 1.0).  No element of a W row exceeds its row's norm (exact columns hold c_t |c| / |c_H| <= |c|, folded
+// columns the L2 norm of their terms, scaled alike), so S = 127 / (the largest row norm) never overflows a byte.  A row with a
+// larger norm than any before (un-normalised input, a stream) shrinks S for the WHOLE block -- one threshold serves every pair --
+// and the `packed_bytes` of W packed so far are re-quantised in place (k_head_rescale: still upper bounds).
+int32_t head_fit_scale(apss_handle *h, double norm2, unsigned char *W, int64_t packed_bytes) {
+  if (!h->head_i8) return APSS_OK;
+  const double need = 127.0 / (std::sqrt(std::max(norm2, 1e-30)) * 1.0005);
+  if (h->head_s > 0.f && need >= (double)h->head_s) return APSS_OK;
+  if (h->head_s > 0.f && packed_bytes > 0) {
+    const double target = need / 1.25;  // (room for norms a quarter larger before the next pass over W)
+    const uint32_t den = 65535u;
+    const uint32_t num = (uint32_t)std::min<double>(den, std::ceil(target / (double)h->head_s * den));
+    hipLaunchKernelGGL(k_head_rescale, dim3((unsigned)std::min<int64_t>(8192, ceil_div(packed_bytes, 16 * 256))), dim3(256), 0, h->stream, W,
+                       packed_bytes / 16 * 16, num, den);
+    HIPCHK(h, hipGetLastError());
+    h->head_s = (float)target;
+  } else {
+    h->head_s = (float)need;
+  }
+  return APSS_OK;
+}
+inline void head_pack_rendering(const apss_handle *h, HeadPackArgs &p) {
+  p.i8_scale = h->head_i8 ? h->head_s : 0.f;
+  p.overflow = h->head_ovf.p;
 }
 
 // tail view of rows [row0, row1) of a CSR batch (absolute offsets), appended to `v` as its rows [dst_row0, ..)
@@ -772,8 +826,11 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
   APSS_TRY(ensure(h, h->sub, (size_t)h->idx_rows, (size_t)row0));
   APSS_TRY(ensure(h, h->head_ctr, 4));
   HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
+  if (row0 == 0) APSS_TRY(head_setup_rendering(h));
+  APSS_TRY(head_fit_scale(h, (double)h->store_max_norm2, reinterpret_cast<unsigned char *>(h->W.p), ceil_div(row0, kHeadCTile) * kHeadCTile * kh));
   {
     HeadPackArgs a{};
+    head_pack_rendering(h, a);
     a.rowptr = h->rowptr.p;
     a.idx = h->idx.p;
     a.val = h->val.p;
@@ -802,7 +859,7 @@ int32_t head_pack_store(apss_handle *h, int64_t row0) {
 }
 
 int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_base, const uint16_t *Wq, int64_t wq_rows,
-                 float thr, int64_t n_cand);
+                 float thr, double bound, int64_t n_cand);
 
 // How selective is the dense filter on THIS data: the block's first rows (at most 8192) against its first 512 as queries,
 // stored and re-scored.  Returns the fraction of (q, c != q) elements the filter passes that do NOT reach theta.  (Rows arrive in no
@@ -818,7 +875,10 @@ int32_t head_sample_selectivity(apss_handle *h, double *frac) {
   APSS_TRY(ensure(h, h->head_ctr, 4));
   APSS_TRY(ensure(h, h->counters, kCtrCount));
   HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
+  APSS_TRY(head_setup_rendering(h));
+  APSS_TRY(head_fit_scale(h, (double)h->store_max_norm2, nullptr, 0));
   HeadPackArgs p{};
+  head_pack_rendering(h, p);
   p.rowptr = h->rowptr.p;
   p.idx = h->idx.p;
   p.val = h->val.p;
@@ -851,7 +911,7 @@ int32_t head_sample_selectivity(apss_handle *h, double *frac) {
   a.res_cap = kSampleCap;
   a.counters = h->head_ctr.p + 2;
   const double bound = (double)h->store_max_norm2 * 1.0001 + 1e-6;  // |q||c| <= the largest squared row norm
-  APSS_TRY(run_head(h, a, Q, -1, h->W.p, p.w_pad, (float)(h->cfg.theta - 0.0080 * bound - 1e-5), S));
+  APSS_TRY(run_head(h, a, Q, -1, h->W.p, p.w_pad, (float)(h->cfg.theta - 0.0080 * bound - 1e-5), bound, S));
   unsigned long long c[4];
   HIPCHK(h, hipMemcpyAsync(c, h->head_ctr.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -970,7 +1030,7 @@ int32_t choose_head(apss_handle *h, bool *changed) {
     return APSS_OK;
   };
   for (;;) {
-    k = terms.empty() ? 0 : head_width((int32_t)terms.size(), h->head_fold_w, h->head_exact);  // from here on: the width of a W row
+    k = terms.empty() ? 0 : head_width((int32_t)terms.size(), h->head_fold_w, h->head_exact, head_wants_i8(h));  // from here on: the width of a W row
     const bool differs = k != old_k || terms != old_terms;
     h->head_k = k;
     h->head_terms = terms;
@@ -1202,7 +1262,12 @@ int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
 
 // ---- dense-head filter of one query batch (apss_head.hpp): appends its candidates to the sparse filter's list ----
 int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_base, const uint16_t *Wq, int64_t wq_rows,
-                 float thr, int64_t n_cand) {
+                 float thr, double bound, int64_t n_cand) {
+  // INT8 rendering: integer products, int32 sums -- the only slack is the fp32 arithmetic that made the rows (k_head_pack)
+  const bool i8 = h->head_i8;
+  const double s2 = (double)h->head_s * (double)h->head_s;
+  const int32_t thr_i = i8 ? (int32_t)std::max(1.0, std::floor(s2 * (h->cfg.theta - 2e-5 * (1.0 + bound)))) : 0;
+  const float inv_s2 = i8 ? (float)(1.0 / s2) : 0.f;
   const int kt = h->head_k;                        // width of a W row
   const int kh = std::min(kt, kHeadBlock);        // width of the first block
   const int n_blocks = kt > kHeadBlock ? 2 : 1;
@@ -1220,7 +1285,9 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
     g.n_parts = h->head_parts;
     g.q_ext = a.q_ext;
     g.c_ext = h->ext.p;
-    g.thr = thr;
+    g.thr = i8 ? (float)thr_i : thr;
+    g.i8 = i8 ? 1 : 0;
+    g.inv_s2 = inv_s2;
     g.res_q = a.res_q;
     g.res_c = a.res_c;
     g.res_s = a.res_s;
@@ -1262,6 +1329,8 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
   g.q_ext = a.q_ext;
   g.c_ext = h->ext.p;
   g.thr = thr;
+  g.thr_i = thr_i;
+  g.inv_s2 = inv_s2;
   g.res_q = a.res_q;
   g.res_c = a.res_c;
   g.res_s = a.res_s;
@@ -1283,7 +1352,10 @@ int32_t run_head(apss_handle *h, const ProbeArgs &a, int64_t nq, int64_t q_slot_
       // bound by their epilogue and lose with it: profiles/r03_head_gemm.md)
       // (the folded block has no positive count in its epilogue: there the three-buffer pipeline pays at 128 columns too,
       // 0.60 -> 0.68 of the peak at N = 1M)
-      if (b > 0 && fold_w == 128) hipLaunchKernelGGL((k_head_gemm<128, false, 3>), grid, dim3(512), 0, h->stream, g);
+      // INT8 rendering (one block of 128 | 256 byte-wide columns): v_mfma_i32_32x32x32_i8
+      if (i8 && kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, 3, 8, true>), grid, dim3(512), 0, h->stream, g);
+      else if (i8) hipLaunchKernelGGL((k_head_gemm<256, true, 3, 8, true>), grid, dim3(512), 0, h->stream, g);
+      else if (b > 0 && fold_w == 128) hipLaunchKernelGGL((k_head_gemm<128, false, 3>), grid, dim3(512), 0, h->stream, g);
       else if (b > 0) hipLaunchKernelGGL((k_head_gemm<256, false, 3>), grid, dim3(512), 0, h->stream, g);
       else if (kh == 64) hipLaunchKernelGGL((k_head_gemm<64, true, 2>), grid, dim3(512), 0, h->stream, g);
       else if (kh == 128) hipLaunchKernelGGL((k_head_gemm<128, true, 2>), grid, dim3(512), 0, h->stream, g);
@@ -1967,7 +2039,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       HIPCHK(h, hipMemsetAsync(h->head_ctr.p, 0, 4 * sizeof(unsigned long long), h->stream));
       HIPCHK(h, hipEventRecord(h->ev2, h->stream));
       const bool stored = q_slot_base >= 0;
-      APSS_TRY(run_head(h, a, nq, q_slot_base, stored ? h->W.p : h->q_W.p, stored ? (int64_t)(h->W.cap / h->head_k) : ceil_div(nq, kHeadCTile) * kHeadCTile, head_thr, h->idx_rows));
+      APSS_TRY(run_head(h, a, nq, q_slot_base, stored ? h->W.p : h->q_W.p, stored ? (int64_t)(h->W.cap / h->head_k) : ceil_div(nq, kHeadCTile) * kHeadCTile, head_thr, bound, h->idx_rows));
       HIPCHK(h, hipEventRecord(h->ev3, h->stream));
       HIPCHK(h, hipMemcpyAsync(head_c, h->head_ctr.p, sizeof(head_c), hipMemcpyDeviceToHost, h->stream));
     }
@@ -2148,7 +2220,11 @@ int32_t pack_query_head(apss_handle *h, const int64_t *rowptr, const int32_t *id
   const int64_t q_pad = ceil_div(nq, kHeadCTile) * kHeadCTile;
   APSS_TRY(ensure(h, h->q_W, (size_t)(q_pad * h->head_k)));
   APSS_TRY(ensure(h, h->q_sub, (size_t)nq));
+  // (a query batch with larger norms than the store's shrinks the block's scale: the store's rows are re-quantised)
+  APSS_TRY(head_fit_scale(h, std::max((double)h->store_max_norm2, (double)h->q_max_norm2), reinterpret_cast<unsigned char *>(h->W.p),
+                          ceil_div(h->idx_rows, kHeadCTile) * kHeadCTile * (int64_t)h->head_k));
   HeadPackArgs a{};
+  head_pack_rendering(h, a);
   a.rowptr = rowptr;
   a.idx = idx;
   a.val = val;
@@ -2521,7 +2597,7 @@ int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *term
   HIPCHK(h, hipMemcpyAsync(h->head_pos.p, pos.data(), (size_t)h->cfg.dim * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->head_terms.assign(terms, terms + n_terms);
-  h->head_k = head_width(n_terms, h->head_fold_w, h->head_exact);
+  h->head_k = head_width(n_terms, h->head_fold_w, h->head_exact, head_wants_i8(h));
   h->head_fixed = true;
   h->head_blocked = false;
   h->head_part = part;
