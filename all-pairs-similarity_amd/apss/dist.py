@@ -54,7 +54,7 @@ def term_ranges(df, world):
 def hip_head_chooser(dim, theta, device, head_terms=0, sample_rows=131072):
     """The dense-head block of a sharded join, decided by the library's own policy (choose_head in csrc/apss_hip.hip:
     sampled document frequencies, measured selectivity) on the first `sample_rows` rows of the batch: a plain handle
-    indexes the sample and is asked which terms it took.  head_terms: 0 = policy, 64 | 128 | 256 | 512 | 1024 = that many."""
+    indexes the sample and is asked which terms it took.  head_terms: 0 = policy, N <= 32768 = that many of the most frequent terms."""
     def choose(rp, idx, val):
         from .engine import ApssIndex
         m = int(min(len(rp) - 1, sample_rows))
@@ -178,7 +178,7 @@ class ShardedJoin:
     3.3x (section 7).  `term_shards` = T picks the layout:
     bench.py's headline is T = world (the layout BASELINE.json names), this class's default T = 1.
     head_terms: dense-head block of the term-sharded layouts (module docstring): 0 = the library's policy decides on rank 0,
-    -1 = never, 64 | 128 | 256 | 512 | 1024 = that many of the most frequent terms.  (With T = 1 every handle is a plain one and decides
+    -1 = never, N <= 32768 = that many of the most frequent terms.  (With T = 1 every handle is a plain one and decides
     for itself.)"""
 
     def __init__(self, dim, theta, rank, world, device, tile_rows=0, engine_factory=None, comm_device=None,
@@ -267,7 +267,7 @@ class ShardedJoin:
             self.last = {
                 "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
                 "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
-                "head_terms": st.get("head_terms", 0),
+                "head_terms": st.get("head_terms", 0), "head_int8": st.get("head_int8", 0),
                 "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()), "device_posting_visits": int(tot[3].item()),
                 "exchange": {"term_shards": 1, "candidate_ranges": self.D, "candidates_per_rank": [int(n_mine)],
                              "union": int(n_mine), "all_gather_bytes_per_rank": 0, "all_reduce_bytes": 0,
@@ -304,7 +304,7 @@ class ShardedJoin:
         self.last = {
             "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
             "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
-            "head_terms": int(self.head.size),
+            "head_terms": int(self.head.size), "head_int8": st.get("head_int8", 0),
             "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()), "device_posting_visits": int(tot[3].item()),
             "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes,
                          "union": int(uniq.numel()), "all_gather_bytes_per_rank": 8 * max(sizes + [1]) * self.T,

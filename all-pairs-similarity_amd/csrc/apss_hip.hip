@@ -715,6 +715,9 @@ constexpr double kHeadSparseRate = 8.0e11;  // posting visits / s of the sparse 
 // seconds per (query, candidate) element of the head contraction, block width 64 / 128 / 256 (measured on random rows,
 // profiles/r02_head_gemm.md: 1.65 PFLOP/s at 256; narrower blocks are bound by the epilogue's scan, not by the MFMAs)
 constexpr double kHeadDenseCost[4] = {1.5e-13, 1.9e-13, 3.1e-13, 3.1e-13};  // (last: a head of more than 256 terms -- still ONE block of 256 columns)
+// ... with the INT8 rendering (v_mfma_i32_32x32x32_i8, rows half as wide; round 4: C3-Zipf(1) at N = 1M 155 -> 88 ms, 1.75e-13 per
+// element at 256 columns; a block of up to 64 terms takes 128 byte-wide columns)
+constexpr double kHeadDenseCostI8[4] = {1.2e-13, 1.2e-13, 1.75e-13, 1.75e-13};
 constexpr double kHeadFoldMaxRowTerms = 96.0;  // terms of the folded block a row may hold on average (chance pairs collide in m^2 / 256 columns)
 constexpr double kHeadSurvivorCost = 2.5e-9;  // seconds per element the dense filter passes on (report + de-dup + exact re-score; measured in
                                               // round 3: 5.6e6 more survivors cost 5 ms, i.e. 0.9e-9 each; the sample's TRUE pairs count too)
@@ -980,7 +983,7 @@ int32_t choose_head(apss_handle *h, bool *changed) {
       f_max = std::max(f_max, f);
     }
     const double s2_bound = std::min(s2_all, (double)top * f_max * f_max);
-    hopeless = s2_bound / kHeadSparseRate < 1.5 * 0.5 * kHeadDenseCost[0];
+    hopeless = s2_bound / kHeadSparseRate < 1.5 * 0.5 * (head_wants_i8(h) ? kHeadDenseCostI8 : kHeadDenseCost)[0];
   }
   if (!hopeless) {
     std::nth_element(order.begin(), order.begin() + (ptrdiff_t)top - 1, order.end(), more_frequent);
@@ -1006,7 +1009,7 @@ int32_t choose_head(apss_handle *h, bool *changed) {
       if (m_fold > kHeadFoldMaxRowTerms) break;
       // per N^2 pairs of a stored batch: df_t^2 = f_t^2 N^2 visits saved; half of the product computed (symmetric).  A head
       // of more than 256 terms costs ONE more contraction however many terms fold into it
-      const double save = s2 / kHeadSparseRate, cost = 0.5 * kHeadDenseCost[std::min(ki++, 3)];
+      const double save = s2 / kHeadSparseRate, cost = 0.5 * (head_wants_i8(h) ? kHeadDenseCostI8 : kHeadDenseCost)[std::min(ki++, 3)];
       if (save >= 1.5 * cost && kk == kHeadBlock) gain256 = save - cost;
       if (save >= 1.5 * cost && save - cost > best) {
         best = save - cost;
@@ -1647,6 +1650,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.head_ms = h->st.head_flops = 0;
   h->st.head_terms = h->head_k ? (int64_t)h->head_terms.size() : 0;
   h->st.head_columns = (uint32_t)h->head_k;
+  h->st.head_int8 = h->head_k && h->head_i8 ? 1 : 0;
   if (n_results) *n_results = 0;
   APSS_TRY(ensure(h, h->counters, kCtrCount));
   h->st.filter_survivors = 0;
@@ -1745,7 +1749,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   }
   // a stored batch that still waits in the tail is not in the index: for the join over the index it is an outside batch
   const int64_t q_slot_base = q_slot_first >= 0 && q_slot_first < h->idx_rows ? q_slot_first : -1;
-  if (hybrid_wanted && !(coarse_path && mode == 0 && head_thr >= 0.5 * theta)) {
+  if (hybrid_wanted && !(coarse_path && mode == 0 && (h->head_i8 || head_thr >= 0.5 * theta))) {  // (the INT8 rows carry no rounding bound)
     // this call cannot take the hybrid path (signed or very long queries, norms out of range ...): the dense block's
     // terms go back into the inverted index, for good, and the call runs as on a handle without a block
     if (h->sharded)  // (a shard cannot leave the partition its peers were given)

@@ -35,6 +35,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # ... 6.29 TB/s measured float4 copy
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # ... dense bf16 MFMA peak (no sparsity)
+MFMA_I8_PEAK_TOPS = 5000.0      # ... v_mfma_i32_32x32x32_i8: the cycles of the bf16 form at twice the K, i.e. 2x bf16 per clock
 BYTES_PER_VISIT = 8            # one posting = int32 slot + fp32 weight (the ACCOUNTING unit)
 METRIC = "scored candidate pairs/sec + achieved HBM GB/s, N=1M d=100k nnz=100, 1/2/4/8 GPU"
 
@@ -259,15 +260,18 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
         })
     if hybrid:
         flops = st["head_flops"]
-        out.update({"head_terms": st["head_terms"], "head_pairs_per_step": st["head_pairs"], "head_kernel_ms": head_s * 1e3,
+        out.update({"head_terms": st["head_terms"], "head_int8": int(st.get("head_int8", 0)), "head_pairs_per_step": st["head_pairs"], "head_kernel_ms": head_s * 1e3,
                     "head_survivors": st["head_survivors"],
                     "candidate_pairs_note": "max(pairs sharing a tail term, pairs sharing a head term): a lower bound of "
                                             "the distinct pairs scored (a pair sharing both kinds is scored by both filters)"})
-        head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16)" % (
+        i8 = bool(st.get("head_int8"))
+        peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_BF16_PEAK_TFLOPS
+        head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (%s)" % (
                          min(256, st["head_columns"]), " (one block: 128 terms with a column each + %d terms folded into 128 columns)"
-                         % (st["head_terms"] - 128) if st["head_terms"] > 256 else ""),
-                     "achieved": flops / head_s / 1e12 if head_s > 0 else None, "peak": MFMA_BF16_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": flops / head_s / 1e12 / MFMA_BF16_PEAK_TFLOPS if head_s > 0 else None,
+                         % (st["head_terms"] - 128) if st["head_terms"] > 256 else "",
+                         "v_mfma_i32_32x32x32_i8: INT8 rows rounded up, exact integer filter" if i8 else "v_mfma_f32_32x32x16_bf16"),
+                     "achieved": flops / head_s / 1e12 if head_s > 0 else None, "peak": peak,
+                     "unit": "TOP/s" if i8 else "TFLOP/s", "frac": flops / head_s / 1e12 / peak if head_s > 0 else None,
                      "traffic": None,
                      "flops_note": "2 x KH x (512-slot query blocks x 64-row candidate tiles the grid multiplies; the upper "
                                    "triangle of a stored batch is skipped) per launch / HIP-event kernel time"}
@@ -391,12 +395,15 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
             # skewed terms: the join's dense-head block, cut over the term group's ranks by candidate tile (apss/dist.py)
             nt = sj.last["head_terms"]
             kh = 64 if nt <= 64 else (128 if nt <= 128 else 256)
-            head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (v_mfma_f32_32x32x16_bf16), candidate tiles t %% %d == rank" % (
-                             kh, " (128 terms with a column each + %d folded into 128 columns)" % (nt - 128) if nt > 256 else "", sj.T),
-                         "achieved": head_flops / (hm * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s (per GPU: the slowest rank's kernel and that rank's flops)",
-                         "frac": head_flops / (hm * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None}
-            row.update({"head_terms": sj.last["head_terms"], "head_kernel_ms_slowest_rank": hm})
+            i8 = bool(sj.last.get("head_int8"))
+            peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_BF16_PEAK_TFLOPS
+            head_roof = {"bound": "mfma", "kernel": "k_head_gemm<%d>%s (%s), candidate tiles t %% %d == rank" % (
+                             max(kh, 128) if i8 else kh, " (128 terms with a column each + %d folded into 128 columns)" % (nt - 128) if nt > 256 else "",
+                             "v_mfma_i32_32x32x32_i8: INT8 rows rounded up" if i8 else "v_mfma_f32_32x32x16_bf16", sj.T),
+                         "achieved": head_flops / (hm * 1e-3) / 1e12, "peak": peak,
+                         "unit": "%s (per GPU: the slowest rank's kernel and that rank's operations)" % ("TOP/s" if i8 else "TFLOP/s"),
+                         "frac": head_flops / (hm * 1e-3) / 1e12 / peak, "traffic": None}
+            row.update({"head_terms": sj.last["head_terms"], "head_int8": int(i8), "head_kernel_ms_slowest_rank": hm})
             if hm >= pm:
                 row["roofline"], row["roofline_sparse_filter"] = head_roof, sparse_roof
             else:
@@ -433,7 +440,7 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
         "value_reference_equivalent": head["value_reference_equivalent"],
         "device_share_of_candidate_pairs": head["device_share_of_candidate_pairs"],
     }
-    for k in ("roofline_dense_head", "roofline_sparse_filter", "head_terms", "head_kernel_ms_slowest_rank"):
+    for k in ("roofline_dense_head", "roofline_sparse_filter", "head_terms", "head_int8", "head_kernel_ms_slowest_rank"):
         if k in head:
             out[k] = head[k]
     return out, head["grid"] + "; " + head["collectives"], extra
@@ -617,7 +624,8 @@ def main():
                           "build_ms": eng.stats["build_ms"], "posting_visits": eng.stats["posting_visits"], "device_posting_visits": eng.stats["device_posting_visits"],
                           "candidates": int(n_c), "probe_kernel": eng.stats["probe_kernel"], "head_terms": eng.stats["head_terms"],
                           "head_ms": eng.stats["head_ms"], "head_survivors": eng.stats["head_survivors"],
-                          "head_frac_of_bf16_peak": (eng.stats["head_flops"] / (eng.stats["head_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
+                          "head_int8": eng.stats["head_int8"],
+                          "head_frac_of_mfma_peak": (eng.stats["head_flops"] / (eng.stats["head_ms"] * 1e-3) / 1e12 / (MFMA_I8_PEAK_TOPS if eng.stats["head_int8"] else MFMA_BF16_PEAK_TFLOPS)
                                                      if eng.stats["head_ms"] > 0 else None),
                           "algorithmic_frac": BYTES_PER_VISIT * eng.stats["device_posting_visits"] / (eng.stats["probe_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}))
         wd.done()
@@ -646,7 +654,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if (world > 1 or group_engine) else "weak",
             "vs_baseline": None,
-            "dtype": "u16+f32" if not body.get("head_terms") else "u16+bf16+f32",  # 16-bit fixed-point filter sums (+ bf16 MFMA head filter), fp32 exact rescoring
+            # 16-bit fixed-point filter sums (+ the MFMA head filter: INT8 rows rounded up, or bf16), fp32 exact rescoring
+            "dtype": "u16+f32" if not body.get("head_terms") else ("u16+i8+f32" if body.get("head_int8") else "u16+bf16+f32"),
             "data": "synthetic",
             "config": {"workload": "%s: N=%d dim=%d nnz=%d %s theta=%g, single-batch self-join (build + probe)" % (
                 a.workload, n, cfg["dim"], cfg["nnz"], "Zipf(%g)" % cfg["zipf_s"] if cfg["zipf_s"] else "uniform",

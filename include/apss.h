@@ -76,8 +76,9 @@ typedef struct apss_config {
                               N <= 32768 = always the N most frequent terms.  Up to 256 terms: a column each.  More: ONE block of
                               256 columns, the 128 most frequent terms with a column each, the others FOLDED into the other 128
                               (several terms add into one column: an upper bound of their partial score for non-negative
-                              weights).  Terms in the block are scored by a bf16 MFMA contraction instead of their posting
-                              lists; results are the same set */
+                              weights).  Terms in the block are scored by an MFMA contraction instead of their posting lists --
+                              over INT8 rows rounded UP (a sound filter: integer products, int32 sums) or bf16 rows
+                              (apss_stats.head_int8); survivors are re-scored exactly: results are the same set */
   int64_t capacity_rows;   /* hints for the initial HBM reservation (0 = grow on demand) */
   int64_t capacity_nnz;
 } apss_config;
@@ -120,7 +121,8 @@ typedef struct apss_stats {
   int32_t query_chunk;      /* query rows per workgroup of the last probe launch (the symmetric join needs a power of two that
                                divides filter_tile_rows) */
   int32_t filter_tile_rows; /* candidate rows per tile of the index rendering the last probe ran over */
-  int32_t reserved0;
+  int32_t head_int8;        /* 1: the dense-head block's rows are the INT8 rendering (rounded up; v_mfma_i32_32x32x32_i8: head_flops are
+                               integer operations then, against twice the bf16 peak), 0: bf16 */
 } apss_stats;
 
 /* apss_stats.symmetric_declined */

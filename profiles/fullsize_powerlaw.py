@@ -72,10 +72,11 @@ def run(n, dim, nnz, theta, seed=20245, head_terms=0, zipf_s=1.0, log=sys.stderr
         q, c, s = ix.fetch()
         out.update({k: st[k] for k in ("tiles", "posting_visits", "device_posting_visits", "symmetric", "candidate_pairs", "result_pairs", "probe_ms", "build_ms",
                                        "probe_launches", "filter_survivors", "rescore_ms", "hbm_bytes", "head_terms", "head_pairs",
-                                       "head_survivors", "head_ms", "head_flops", "probe_kernel")})
+                                       "head_survivors", "head_ms", "head_flops", "head_int8", "probe_kernel")})
     out["wall_s"] = wall
     out["scored_pairs_per_s"] = max(st["candidate_pairs"], st["head_pairs"]) / wall
-    out["head_frac_of_bf16_peak"] = st["head_flops"] / (st["head_ms"] * 1e-3) / 2.5e15 if st["head_ms"] > 0 else None
+    # (INT8 rendering: integer operations against the int8 MFMA peak, 2 x the bf16 peak)
+    out["head_frac_of_mfma_peak"] = st["head_flops"] / (st["head_ms"] * 1e-3) / (5.0e15 if st["head_int8"] else 2.5e15) if st["head_ms"] > 0 else None
     out["tail_algorithmic_frac"] = 8.0 * st["device_posting_visits"] / (st["probe_ms"] * 1e-3) / 8e12 if st["probe_ms"] > 0 else None  # (visits the kernels made)
     return check_pairs(out, n, theta, idx, val, src, torch.from_numpy(q).to(dev), torch.from_numpy(c).to(dev),
                        torch.from_numpy(s).to(dev))

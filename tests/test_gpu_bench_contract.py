@@ -65,11 +65,13 @@ def test_bench_skewed_workload_reports_an_mfma_roofline():
     d = _one_line(out)
     for k in DRIVER_KEYS:
         assert k in d, k
-    assert d["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768) and d["head_pairs_per_step"] > 0 and "bf16" in d["dtype"]
+    assert d["head_terms"] in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768) and d["head_pairs_per_step"] > 0
+    # the block's rows are the INT8 rendering (rounded up; v_mfma_i32_32x32x32_i8): priced against the int8 peak, 2 x bf16
+    assert d["head_int8"] == 1 and d["dtype"] == "u16+i8+f32"
     roofs = [d["roofline"]] + [d[k] for k in ("roofline_sparse_filter", "roofline_dense_head") if k in d]
     assert len(roofs) == 2 and {r["bound"] for r in roofs} == {"lds", "mfma"}
     m = [r for r in roofs if r["bound"] == "mfma"][0]
-    assert m["unit"] == "TFLOP/s" and m["peak"] == 2500.0 and 0 < m["frac"] < 1.0 and "k_head_gemm" in m["kernel"]
+    assert m["unit"] == "TOP/s" and m["peak"] == 5000.0 and 0 < m["frac"] < 1.0 and "k_head_gemm" in m["kernel"] and "i8" in m["kernel"]
     assert abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-9
     assert d["value"] > 1e9 and d["result_pairs_per_step"] > 100
 

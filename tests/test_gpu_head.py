@@ -234,3 +234,49 @@ def test_power_law_property_without_the_oracle_reduced():
     assert out["missing"] == 0 and out["planted_pairs_required"] > 5000 and out["max_abs_score_error"] <= 1e-5
     assert out["head_terms"] >= 256 and out["head_pairs"] > 0.9 * out["pairs_n_squared"]
     assert out["posting_visits"] < 0.01 * out["posting_visits_all_sparse"]  # the head took the long posting lists
+
+
+def test_int8_and_bf16_renderings_of_the_block_give_the_same_pairs(engine, oracle, monkeypatch):
+    """the block's rows as INT8 rounded UP (the default: v_mfma_i32_32x32x32_i8, integer sums, no rounding bound) and as bf16
+    (APSS_DEBUG=head_bf16): the same result list, on a folded head too; the INT8 filter passes hardly more than the bf16 one"""
+    n, dim, nnz, theta = 6000, 4000, 40, 0.55
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=77, dup_frac=0.1)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    for kh in (100, 256, 2000):
+        got8, st8 = _join(engine, dim, theta, rp, idx, val, head_terms=kh)
+        monkeypatch.setenv("APSS_DEBUG", "head_bf16")
+        got16, st16 = _join(engine, dim, theta, rp, idx, val, head_terms=kh)
+        monkeypatch.delenv("APSS_DEBUG")
+        assert st8["head_int8"] == 1 and st16["head_int8"] == 0 and st8["head_columns"] == (128 if kh <= 128 else 256)
+        assert_same_pairs(got8, want, theta)
+        assert got8.keys() == got16.keys()
+        assert st8["head_survivors"] <= 1.5 * st16["head_survivors"] + 100
+        assert st8["head_pairs"] == st16["head_pairs"]  # pairs sharing a head term: a positive integer sum iff a positive product
+
+
+def test_int8_block_follows_growing_row_norms(engine, oracle):
+    """un-normalised rows streamed with norms that grow from batch to batch (1, 1.6, 2.4, 3.5) and an outside query batch larger
+    still: the INT8 scale S = 127 / (largest norm) shrinks for the WHOLE block and the rows packed so far are re-quantised in
+    place (k_head_rescale: still upper bounds); every batch's answer equals the oracle worker's"""
+    n, dim, nnz = 4000, 1500, 16
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0, seed=19, dup_frac=0.15)
+    theta = 0.6
+    cuts = [0, 1000, 1800, 2500, 3200]
+    grow = [1.0, 1.6, 2.4, 3.5]
+    w = oracle.Worker(dim, theta)
+    with engine.ApssIndex(dim, theta, head_terms=300) as ix:
+        for (b0, b1), f in zip(zip(cuts[:-1], cuts[1:]), grow):
+            sl = slice(rp[b0], rp[b1])
+            args = (np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl] * f)
+            want = to_map(*w.index_data(*args))
+            got = to_map(*ix.insert_and_query(*args))
+            assert ix.stats()["head_int8"] == 1 and ix.stats()["head_terms"] == 300
+            assert_same_pairs(got, want, theta, band=5e-5, tol=5e-5)  # scores up to 12: fp32 sums
+        b0, b1 = 3200, 4000
+        sl = slice(rp[b0], rp[b1])
+        args = (np.arange(b0, b1), rp[b0:b1 + 1] - rp[b0], idx[sl], val[sl] * 4.5)
+        want = to_map(*w.index_data(*args, query_only=True))
+        got = to_map(*ix.query(*args))
+        assert_same_pairs(got, want, theta, band=1e-4, tol=1e-4)
+        from apss import _lib
+        assert not (ix.stats()["downgrades"] & _lib.DOWNGRADE_HEAD) and ix.stats()["head_int8"] == 1  # (the block stayed, in INT8)

@@ -189,10 +189,15 @@ def _bf16_round_down_loss(x):
     return (float(np.float32(x)) - y) / float(np.float32(x))
 
 
-def test_dense_head_filter_at_the_worst_case_of_bf16_rounding(engine, oracle):
+@pytest.mark.parametrize("rendering", ["int8", "head_bf16"])
+def test_dense_head_filter_at_the_worst_case_of_bf16_rounding(engine, oracle, monkeypatch, rendering):
     """the dense-head filter's threshold is theta - 0.0080 max|q||c|: bf16 round-to-nearest may lower each factor of a
     product by up to 2^-8.  Pairs built to sit right there: rows whose head part is k equal entries with 1/sqrt(k) just
     below a bf16 rounding midpoint (every entry of W rounds DOWN by nearly 2^-8), scores a hair above theta; all found"""
+    # (both renderings of the block: bf16 rows with the threshold lowered by the rounding bound, and the default INT8 rows
+    # rounded UP -- integer products, no bound at all; the pairs at theta (1 + 3e-5) test the fp32 arithmetic that makes them)
+    if rendering != "int8":
+        monkeypatch.setenv("APSS_DEBUG", rendering)
     # k whose 1/sqrt(k) loses the most in bf16
     k = max(range(8, 65), key=lambda kk: _bf16_round_down_loss(1.0 / np.sqrt(kk)))
     loss = _bf16_round_down_loss(1.0 / np.sqrt(k))
@@ -219,13 +224,13 @@ def test_dense_head_filter_at_the_worst_case_of_bf16_rounding(engine, oracle):
     with engine.ApssIndex(dim, theta, head_terms=64) as ix:
         got = to_map(*ix.insert_and_query(np.arange(n), rp, idx, val))
         st = ix.stats()
-    assert st["head_terms"] == 64 and st["head_survivors"] >= len(near)
+    assert st["head_terms"] == 64 and st["head_survivors"] >= len(near) and st["head_int8"] == (1 if rendering == "int8" else 0)
     missing = [kq for kq in want if kq not in got and abs(want[kq] - theta) > 1e-5]
     assert not missing, (len(missing), missing[:3])
     assert all(kq in want or abs(v - theta) <= 1e-5 for kq, v in got.items())
 
 
-@pytest.mark.parametrize("geometry", ["default", "fold_w=256", "fold_w=128", "mix=64"])
+@pytest.mark.parametrize("geometry", ["default", "head_bf16", "fold_w=256", "fold_w=128", "mix=64", "mix=64,head_bf16"])
 def test_folded_head_columns_at_the_worst_case_of_bf16_rounding(engine, oracle, monkeypatch, geometry):
     """the same attack on the FOLDED columns of a wide head (terms beyond the first `exact` add into shared columns; the test is
     an upper bound of the head's partial score only as long as rounding cannot take it below theta): pairs whose whole mass
@@ -235,7 +240,8 @@ def test_folded_head_columns_at_the_worst_case_of_bf16_rounding(engine, oracle, 
     split of it, and the two-block forms kept for comparison"""
     if geometry != "default":
         monkeypatch.setenv("APSS_DEBUG", geometry)
-    exact, fold = {"default": (128, 128), "fold_w=256": (256, 256), "fold_w=128": (256, 128), "mix=64": (64, 192)}[geometry]
+    exact, fold = {"default": (128, 128), "head_bf16": (128, 128), "fold_w=256": (256, 256), "fold_w=128": (256, 128), "mix=64": (64, 192),
+                   "mix=64,head_bf16": (64, 192)}[geometry]
     k = max(range(8, 65), key=lambda kk: _bf16_round_down_loss(1.0 / np.sqrt(kk)))
     dim, theta, n_head = 6000, 0.8, 256 + 4 * fold
     rng = np.random.default_rng(9)
