@@ -390,6 +390,7 @@ template <> struct HeadMma<false> {
   static __device__ __forceinline__ elem thr(const HeadGemmArgs &a) { return a.thr; }
   static __device__ __forceinline__ float score(const HeadGemmArgs &, elem v) { return v; }
   static __device__ __forceinline__ elem vmax(elem x, elem y) { return fmaxf(x, y); }
+  static __device__ __forceinline__ elem vmax3(elem x, elem y, elem z) { return __builtin_fmaxf(__builtin_fmaxf(x, y), z); }
 };
 template <> struct HeadMma<true> {
   using frag = apss_i32x4;
@@ -399,6 +400,7 @@ template <> struct HeadMma<true> {
   static __device__ __forceinline__ elem thr(const HeadGemmArgs &a) { return a.thr_i; }
   static __device__ __forceinline__ float score(const HeadGemmArgs &a, elem v) { return (float)v * a.inv_s2; }
   static __device__ __forceinline__ elem vmax(elem x, elem y) { return max(x, y); }
+  static __device__ __forceinline__ elem vmax3(elem x, elem y, elem z) { return max(max(x, y), z); }
 };
 
 template <int KH, bool COUNT = true, int NBUF = 3, int NW = 8, bool I8 = false>
@@ -499,12 +501,22 @@ __global__ __launch_bounds__(64 * NW, 2) void k_head_gemm(const HeadGemmArgs a) 
 #ifdef APSS_GEMM_NOEPI  // (microbenchmark experiment only: the tile stream without its epilogue; results are garbage)
     if (step != 0) return;
 #endif
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = 2 * step + j;
-      const elem_t v = ac[e >> 4][e & 15];
-      hf.mx = MM::vmax(hf.mx, v);
-      if (COUNT) hf.pos += v > (elem_t)0 ? 1u : 0u;
+    // two accumulator elements per call.  The block's weights are non-negative, so is every accumulator, and "positive" is "bit
+    // pattern != 0" in either rendering: min(bits, 1) twice and ONE three-operand add count the pair in 1.5 vector instructions
+    // per element (compare + add-with-carry: 2), v_max3 takes the pair's maximum in one.  (Round 4, SQ counters on power-law C5:
+    // with the INT8 rendering a half carries half the MFMAs over the same 32 accumulators and the epilogue's 5.9 vector
+    // instructions per MFMA had become what the matrix pipe waits for.  Counting per WAVE on the scalar unit -- ballot,
+    // s_bcnt1, s_add -- measured slower again: 88 -> 104 ms on C3-Zipf(1), as in round 2.)
+    const elem_t v0 = ac[(2 * step) >> 4][(2 * step) & 15], v1 = ac[(2 * step + 1) >> 4][(2 * step + 1) & 15];
+    hf.mx = MM::vmax3(hf.mx, v0, v1);
+    if constexpr (COUNT && !I8) {
+      hf.pos += (v0 > (elem_t)0 ? 1u : 0u) + (v1 > (elem_t)0 ? 1u : 0u);  // (bf16 form: twice the MFMAs per element, the compare form is no slower)
+    } else if constexpr (COUNT) {
+      // (spelled in assembly: the compiler folds min(x, 1) back into compare + conditional add)
+      uint32_t t0, t1;
+      asm("v_min_u32 %0, 1, %1" : "=v"(t0) : "v"(__builtin_bit_cast(uint32_t, v0)));
+      asm("v_min_u32 %0, 1, %1" : "=v"(t1) : "v"(__builtin_bit_cast(uint32_t, v1)));
+      asm("v_add3_u32 %0, %1, %2, %3" : "=v"(hf.pos) : "v"(t0), "v"(t1), "v"(hf.pos));
     }
   };
   auto finish = [&](Half &hf, const acc_t (&ac)[2], const int64_t cb_row0) {  // cb_row0: the half's first candidate row
