@@ -60,6 +60,7 @@ struct DebugCfg {
   int mix = 0;                 // mix=E          ONE head block of 256 columns: E terms with a column each, the others folded into 256 - E
   bool no_chain = false;       // no_chain       small batches take the exact pass with its own host round trips (as large ones do)
   bool no_append = false;      // no_append      a batch that lands in a partly filled tile rebuilds the whole tile (never appends to it)
+  int res_cap = 0;             // res_cap=N      initial capacity of the candidate list (tests of the overflow -> regrow -> re-run path)
   bool head_bf16 = false;      // head_bf16      the dense-head block keeps bf16 rows (v_mfma_f32_32x32x16_bf16), never the INT8 rendering
 };
 
@@ -103,6 +104,7 @@ DebugCfg parse_debug_env() {
     else if (key == "no_chain") d.no_chain = val != 0;
     else if (key == "no_append") d.no_append = val != 0;
     else if (key == "head_bf16") d.head_bf16 = val != 0;
+    else if (key == "res_cap") d.res_cap = val;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -1904,7 +1906,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   else if (hybrid_wanted && h->sharded)  // (a shard was given its head: no sample of its own; power-law C5 measured ~1 per query and shard)
     want_cap = std::min<int64_t>(want_cap + 6 * nq, 1LL << 30);
   if (h->res_q.cap < (size_t)want_cap) {
-    const size_t cap0 = (size_t)std::max<int64_t>(1 << 20, want_cap);
+    const size_t cap0 = (size_t)(dbg.res_cap > 0 ? dbg.res_cap : std::max<int64_t>(1 << 20, want_cap));  // (res_cap: test hook, forces the regrowth path)
     APSS_TRY(ensure(h, h->res_q, cap0, 0, true));
     APSS_TRY(ensure(h, h->res_c, cap0, 0, true));
     APSS_TRY(ensure(h, h->res_s, cap0, 0, true));
@@ -2087,7 +2089,15 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
     }
     if (c[kCtrResults] > a.res_cap) {
       // the result list overflowed: grow to what the run asked for and repeat the (idempotent) probe
-      const size_t need = (size_t)c[kCtrResults] + (size_t)c[kCtrResults] / 8 + 1024;
+      size_t need = (size_t)c[kCtrResults] + (size_t)c[kCtrResults] / 8 + 1024;
+      if (tri) {
+        // a symmetric run whose FILTER overflowed mirrored only what the list held: the counter under-reports.  What the run
+        // needs is known all the same: the filter's own count (kCtrSnap, taken before the mirror) twice over, plus what the
+        // dense half appended -- asked for at once, instead of one more overflow per stage (each retry is a whole probe)
+        const size_t snap = (size_t)c[kCtrSnap];
+        const size_t head_part = hybrid && c[kCtrResults] > sparse_results ? (size_t)(c[kCtrResults] - sparse_results) : 0;
+        need = std::max(need, 2 * snap + head_part + (2 * snap + head_part) / 8 + 1024);
+      }
       APSS_TRY(ensure(h, h->res_q, need, 0, true));
       APSS_TRY(ensure(h, h->res_c, need, 0, true));
       APSS_TRY(ensure(h, h->res_s, need, 0, true));

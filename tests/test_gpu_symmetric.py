@@ -134,3 +134,28 @@ def test_symmetric_join_with_a_dense_head_block(oracle):
     assert st["head_terms"] == 64 and st["symmetric"] == 1, st
     assert q.size == len(to_map(q, c, s))  # no pair twice
     assert_same_pairs(to_map(q, c, s), want, theta)
+
+
+@pytest.mark.parametrize("head", [-1, 64])
+def test_candidate_list_overflow_on_a_symmetric_join_regrows_once(oracle, monkeypatch, head):
+    """the candidate list overflows in the FILTER stage of a symmetric run (APSS_DEBUG=res_cap=500: small tests never exceed the
+    library's 2^20 entries): the mirror kernel has then copied only what the list held and the counter under-reports -- the
+    regrowth is sized from the filter's own count (twice over: the mirrored half) plus the dense half's survivors, so the run
+    is repeated ONCE, not once per stage; same list as a run that never overflowed, with and without a dense-head block"""
+    from apss.engine import ApssIndex
+    theta, n = 0.7, 6000
+    dim, rp, idx, val = _mixed_batch(n, seed=811)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 1500
+    ids = np.arange(n, dtype=np.int64)
+    with ApssIndex(dim, theta, head_terms=head, tile_rows=256) as ix:
+        ref = to_map(*ix.insert_and_query(ids, rp, idx, val))
+        st0 = ix.stats()
+    monkeypatch.setenv("APSS_DEBUG", "res_cap=500")
+    with ApssIndex(dim, theta, head_terms=head, tile_rows=256) as ix:
+        got = to_map(*ix.insert_and_query(ids, rp, idx, val))
+        st = ix.stats()
+    assert st["symmetric"] == 1 and st0["symmetric"] == 1 and st["head_terms"] == max(head, 0)
+    assert got == ref and st["filter_survivors"] == st0["filter_survivors"] > 500
+    assert st["probe_launches"] == 2 * st0["probe_launches"]  # one overflowing attempt + one that fits
+    assert_same_pairs(got, want, theta)
