@@ -92,9 +92,14 @@ class HipShardEngine:
         # run on torch's stream: the tensors handed to the library are produced by torch kernels on that stream
         self.ix.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
-    def load(self, rp, idx, val, row_range=None, device_arrays=None):
+    def load(self, rp, idx, val, row_range=None, device_arrays=None, query_spans=None):
         """the batch as host CSR (numpy), or already resident: device_arrays = (rowptr int64, idx int32, val fp32) on
-        this engine's GPU (several shard engines of one process then share one copy)"""
+        this engine's GPU (several shard engines of one process then share one copy).
+        query_spans (with a row_range): the SYMMETRIC scheme across row ranges -- this cell joins its own rows with themselves
+        (a whole-store join of the handle: symmetric inside, csrc DESIGN 5c) and meets only the rows of `query_spans`, a list of
+        (row0, row1) spans = the ranges it owns the cross pairs with, as an outside batch; the pairs it finds there stand for
+        both directions (the score is symmetric) and are mirrored by the caller.  Without it the cell meets EVERY row of the
+        batch as a query (each cross pair is then found twice over the grid, once per direction)."""
         dev = self.device
         if device_arrays is not None:
             self.d_rp, self.d_idx, self.d_val = device_arrays
@@ -112,7 +117,99 @@ class HipShardEngine:
             self.s_idx = self.d_idx[e0:e1].contiguous()
             self.s_val = self.d_val[e0:e1].contiguous()
             self.s_ids = self.d_ids[self.r0:self.r1].contiguous()
+        self.sym = (not self.whole) and query_spans is not None
+        if self.sym:  # the outside batch: the rows of the spans, in span order, as their own CSR
+            spans = [(int(a), int(b)) for a, b in query_spans if b > a]
+            self.o_rows = torch.cat([torch.arange(a, b, dtype=torch.int64, device=dev) for a, b in spans]) if spans else \
+                torch.zeros(0, dtype=torch.int64, device=dev)
+            lens = (self.d_rp[1:] - self.d_rp[:-1])[self.o_rows]
+            self.o_rp = torch.zeros(self.o_rows.numel() + 1, dtype=torch.int64, device=dev)
+            if self.o_rows.numel():
+                self.o_rp[1:] = torch.cumsum(lens, 0)
+            parts_i, parts_v = [], []
+            for a, b in spans:
+                e0, e1 = int(self.d_rp[a].item()), int(self.d_rp[b].item())
+                parts_i.append(self.d_idx[e0:e1])
+                parts_v.append(self.d_val[e0:e1])
+            self.o_idx = torch.cat(parts_i).contiguous() if parts_i else torch.zeros(0, dtype=torch.int32, device=dev)
+            self.o_val = torch.cat(parts_v).contiguous() if parts_v else torch.zeros(0, dtype=torch.float32, device=dev)
+            self.o_ids = self.o_rows.contiguous()
+        self.phase = None
         torch.cuda.synchronize()
+
+    def phases(self):
+        """the handle calls of one step: one for a cell that meets the whole batch, two under the symmetric scheme"""
+        return ("own", "outside") if self.sym else ("all",)
+
+    def _merge_stats(self, st, factor):
+        """statistics of a step add up over its phases; posting_visits / candidate_pairs keep counting what the reference's
+        two-directional probe visits, so a mirrored phase counts twice there and once in device_posting_visits"""
+        if not hasattr(self, "stats") or self.stats is None or self._fresh:
+            self.stats = dict(st)
+            for k in ("posting_visits", "candidate_pairs"):
+                self.stats[k] = factor * st[k]
+            self._fresh = False
+            return
+        for k in ("posting_visits", "candidate_pairs"):
+            self.stats[k] += factor * st[k]
+        # (build_ms is the last insert's: the own phase's, counted there)
+        for k in ("device_posting_visits", "probe_ms", "head_ms", "head_flops", "thin_launches", "probe_launches", "head_survivors",
+                  "filter_survivors", "rescore_ms"):
+            self.stats[k] += st[k]
+
+    def run_phase(self, phase):
+        """one handle call of the step; returns the number of pairs it reports (they stay on the device)"""
+        self.phase = phase
+        if phase == "own":
+            self.ix.clear()
+            self._fresh = True
+            n = self.ix.insert_and_query_dev(self.s_ids, self.s_rp, self.s_idx, self.s_val)
+            self._merge_stats(self.ix.stats(), 1)
+            assert self.ix.stats()["rows"] == self.r1 - self.r0, "shard engine: the handle dropped rows"
+            return n
+        if phase == "outside":
+            n = self.ix.query_dev(self.o_ids, self.o_rp, self.o_idx, self.o_val) if self.o_rows.numel() else 0
+            if self.o_rows.numel():
+                self._merge_stats(self.ix.stats(), 2)
+            return n
+        self._fresh = True
+        return self.join()
+
+    def phase_pairs(self, n):
+        """(query row, candidate row) of the phase just run, global rows, + the handle's scores"""
+        q = torch.empty(n, dtype=torch.int32, device=self.device)
+        c = torch.empty(n, dtype=torch.int32, device=self.device)
+        sc = torch.empty(n, dtype=torch.float32, device=self.device)
+        if n:
+            self.ix.results_to(q, c, sc)
+        self.scores = sc
+        q = q.to(torch.int64)
+        if self.phase == "own":
+            q = q + self.r0
+        elif self.phase == "outside":
+            q = self.o_rows[q]
+        return q, c.to(torch.int64) + self.r0
+
+    def phase_partial(self, q_row, c_row):
+        """exact partial scores of pairs of the phase just run (the handle scores against its LAST query batch)"""
+        if self.phase == "own":
+            ql = q_row - self.r0
+        elif self.phase == "outside":
+            ql = torch.searchsorted(self.o_rows, q_row) if self._o_sorted() else self._o_lookup(q_row)
+        else:
+            ql = q_row
+        out = torch.empty(q_row.numel(), dtype=torch.float32, device=self.device)
+        if q_row.numel():
+            self.ix.partial_scores_dev(ql.to(torch.int32).contiguous(), (c_row - self.r0).to(torch.int32).contiguous(), out)
+        return out
+
+    def _o_sorted(self):
+        return bool((self.o_rows[1:] > self.o_rows[:-1]).all().item()) if self.o_rows.numel() > 1 else True
+
+    def _o_lookup(self, q_row):
+        inv = torch.full((self.n,), -1, dtype=torch.int64, device=self.device)
+        inv[self.o_rows] = torch.arange(self.o_rows.numel(), dtype=torch.int64, device=self.device)
+        return inv[q_row]
 
     def join(self):
         """rebuild the shard's index and run its join; returns the number of pairs it reports (they stay on the device)"""
@@ -123,6 +220,7 @@ class HipShardEngine:
             self.ix.insert_dev(self.s_ids, self.s_rp, self.s_idx, self.s_val)
             n = self.ix.query_dev(self.d_ids, self.d_rp, self.d_idx, self.d_val)
         self.stats = self.ix.stats()
+        self.phase = "all"
         # query row == batch row and candidate slot == row - r0 only while ingest keeps every row (no admission filter here)
         assert self.stats["rows"] == self.r1 - self.r0, "shard engine: the handle dropped rows"
         return n
@@ -166,6 +264,19 @@ def join_shards_local(engines, n, theta):
     return uq[keep].cpu().numpy(), uc[keep].cpu().numpy(), total[keep].cpu().numpy(), [int(k.numel()) for k in keys]
 
 
+def half_spans(n, D, j):
+    """The row ranges cell j of D owns the CROSS pairs with (symmetric scheme, D > 1): a pair of rows in two different ranges
+    a, b is probed by exactly one of the two cells -- range j takes the (D - 1) // 2 ranges before it (cyclically) and, for even
+    D, the range opposite to it when it is the lower-numbered of the two -- and reported in both directions."""
+    ranges = [(n * k // D, n * (k + 1) // D) for k in range(D)]
+    mine = [(j - d) % D for d in range(1, (D - 1) // 2 + 1)]
+    if D % 2 == 0 and D > 1:
+        k = (j + D // 2) % D
+        if j < k:
+            mine.append(k)
+    return [ranges[k] for k in sorted(mine)]
+
+
 class ShardedJoin:
     """world = T x D ranks: rank r owns term range (r % T) of the candidate rows in row range (r // T).
 
@@ -173,16 +284,16 @@ class ShardedJoin:
     (the exchange the term-sharded index needs); the D candidate ranges are independent (their result sets are
     disjoint).  A term shard has 1/T of the posting visits of every (query, tile) round but the same number of rounds,
     so its speed-up trails T; candidate ranges need no data-path collective.  A shard that holds ALL rows (D = 1) joins its
-    batch symmetrically (half the rounds), a row-range cell meets its queries as an outside batch and
-    does not: measured one shard at a time on uniform C3, T = 8 is 3.8x one GPU before the exchange, eight candidate ranges
-    3.3x (section 7).  `term_shards` = T picks the layout:
+    batch symmetrically (half the rounds); with D > 1 the symmetry is used ACROSS the row ranges too
+    (round 4): a cell joins its own rows with themselves and meets the rows of only half of the other ranges as an outside
+    batch -- a cross pair is probed by one of its two cells and reported in both directions (half_spans; symmetric_ranges).  `term_shards` = T picks the layout:
     bench.py's headline is T = world (the layout BASELINE.json names), this class's default T = 1.
     head_terms: dense-head block of the term-sharded layouts (module docstring): 0 = the library's policy decides on rank 0,
     -1 = never, N <= 32768 = that many of the most frequent terms.  (With T = 1 every handle is a plain one and decides
     for itself.)"""
 
     def __init__(self, dim, theta, rank, world, device, tile_rows=0, engine_factory=None, comm_device=None,
-                 term_shards=None, head_terms=0, head_chooser=None):
+                 term_shards=None, head_terms=0, head_chooser=None, symmetric_ranges=True):
         self.dim, self.theta, self.rank, self.world, self.device = dim, float(theta), rank, world, device
         # collectives run on `comm_device` tensors: the GPU itself under RCCL, the CPU when rehearsing with gloo
         self.comm = comm_device or device
@@ -203,6 +314,9 @@ class ShardedJoin:
         self.head_chooser = head_chooser or hip_head_chooser(dim, theta, device, max(0, head_terms))
         self.head = np.zeros(0, np.int32)
         self.head_fold = 0
+        # D > 1: a cell joins its own rows symmetrically and meets only HALF of the other ranges' rows as queries, reporting those
+        # pairs in both directions (half_spans); False = every cell meets every row (each cross pair found once per direction)
+        self.symmetric_ranges = symmetric_ranges
         self.last = {}
 
     def _decide_head(self, rp, idx, val):
@@ -240,7 +354,12 @@ class ShardedJoin:
             self.engine = self.engine_factory(self.term_range, head=(self.head, self.ti, self.T, self.head_fold))
         else:
             self.engine = self.engine_factory(self.term_range)
-        self.engine.load(rp, idx, val, None if self.D == 1 else self.row_range)
+        if self.D == 1:
+            self.engine.load(rp, idx, val, None)
+        elif self.symmetric_ranges:
+            self.engine.load(rp, idx, val, self.row_range, query_spans=self.half_spans())
+        else:
+            self.engine.load(rp, idx, val, self.row_range)
 
     def _all_gather_var(self, t):
         """all-gather (inside the term group) of 1-D int64 tensors of different lengths"""
@@ -255,48 +374,64 @@ class ShardedJoin:
         dist.all_gather(out, buf, group=self.group)
         return torch.cat([o[:s] for o, s in zip(out, sizes)]).to(self.device), sizes
 
+    def half_spans(self):
+        return half_spans(self.n, self.D, self.dj)
+
+    def _exchange(self, q, c, partial):
+        """steps 2-4 inside the term group: all-gather of candidate lists, union, exact partial scores, all-reduce, threshold"""
+        key = q.to(torch.int64) * self.n + c.to(torch.int64)
+        allk, sizes = self._all_gather_var(key)
+        uniq = torch.unique(allk)  # sorted: every rank of the group sees the same order
+        uq = torch.div(uniq, self.n, rounding_mode="floor")
+        uc = uniq - uq * self.n
+        part = partial(uq, uc).to(self.comm)
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)  # RCCL all-reduce of partial scores
+        part = part.to(self.device)
+        return uq, uc, part, part >= self.theta, sizes, int(uniq.numel())
+
     def step(self, return_pairs=False):
-        if self.T == 1 and not return_pairs and hasattr(self.engine, "join"):
-            # candidate ranges only: the handle's answer is final; count it without bringing the pairs to the host
-            n_mine = self.engine.join()
-            st = self.engine.stats
-            tot = torch.tensor([float(st.get("posting_visits", 0)), float(st.get("candidate_pairs", 0)), float(n_mine),
-                                float(st.get("device_posting_visits", st.get("posting_visits", 0)))], dtype=torch.float64, device=self.comm)
-            if self.world > 1:
-                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            self.last = {
-                "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
-                "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
-                "head_terms": st.get("head_terms", 0), "head_int8": st.get("head_int8", 0),
-                "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()), "device_posting_visits": int(tot[3].item()),
-                "exchange": {"term_shards": 1, "candidate_ranges": self.D, "candidates_per_rank": [int(n_mine)],
-                             "union": int(n_mine), "all_gather_bytes_per_rank": 0, "all_reduce_bytes": 0,
-                             "term_ranges": self.ranges},
-            }
-            return int(tot[2].item())
-        q, c = self.engine.candidates()
-        if self.T == 1:
-            # the handle holds the whole term space: its answer for this candidate range is already exact and pruned
-            uq, uc, sizes = q, c, [int(q.numel())]
-            uniq = q
-            sc = getattr(self.engine, "scores", None)
-            part = torch.as_tensor(sc, dtype=torch.float32, device=self.device) if sc is not None \
-                else self.engine.partial(uq, uc)
-            keep = torch.ones(q.numel(), dtype=torch.bool, device=self.device) if sc is not None else part >= self.theta
-        else:
-            key = q.to(torch.int64) * self.n + c.to(torch.int64)
-            allk, sizes = self._all_gather_var(key)
-            uniq = torch.unique(allk)  # sorted: every rank of the group sees the same order
-            uq = torch.div(uniq, self.n, rounding_mode="floor")
-            uc = uniq - uq * self.n
-            part = self.engine.partial(uq, uc)
-            part = part.to(self.comm)
-            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)  # RCCL all-reduce of partial scores
-            part = part.to(self.device)
-            keep = part >= self.theta
-        st = getattr(self.engine, "stats", {}) or {}
+        eng = self.engine
+        phased = hasattr(eng, "phases")
+        phases = eng.phases() if phased else ("all",)
+        out_q, out_c, out_s = [], [], []
+        mine, sizes_all, union_all = 0.0, [], 0
+        for ph in phases:
+            mirrored = ph == "outside"  # the pairs of this phase stand for both directions (half_spans)
+            if phased:
+                n_ph = eng.run_phase(ph)
+                if self.T == 1 and not return_pairs:  # candidate ranges only: the handle's answer is final; count it on the device side
+                    mine += (2.0 if mirrored else 1.0) * float(n_ph)
+                    sizes_all.append(int(n_ph))
+                    union_all += int(n_ph)
+                    continue
+                q, c = eng.phase_pairs(n_ph)
+                partial = eng.phase_partial
+            else:
+                q, c = eng.candidates()
+                partial = eng.partial
+            if self.T == 1:
+                # the handle holds the whole term space: its answer for this candidate range is already exact and pruned
+                uq, uc, sizes, n_union = q, c, [int(q.numel())], int(q.numel())
+                sc = getattr(eng, "scores", None)
+                part = torch.as_tensor(sc, dtype=torch.float32, device=self.device) if sc is not None else partial(uq, uc)
+                keep = torch.ones(q.numel(), dtype=torch.bool, device=self.device) if sc is not None else part >= self.theta
+            else:
+                uq, uc, part, keep, sizes, n_union = self._exchange(q, c, partial)
+            sizes_all += sizes
+            union_all += n_union
+            mine += (2.0 if mirrored else 1.0) * float(keep.sum().item()) if self.ti == 0 else 0.0
+            if return_pairs:
+                out_q.append(uq[keep])
+                out_c.append(uc[keep])
+                out_s.append(part[keep])
+                if mirrored:
+                    out_q.append(uc[keep])
+                    out_c.append(uq[keep])
+                    out_s.append(part[keep])
+        if self.T == 1 and not return_pairs and self.ti != 0:
+            mine = 0.0
+        st = getattr(eng, "stats", {}) or {}
         # whole-job counters: posting visits and touched pairs add up over all ranks; result pairs over the D groups
-        mine = float(keep.sum().item()) if self.ti == 0 else 0.0
         tot = torch.tensor([float(st.get("posting_visits", 0)), float(st.get("candidate_pairs", 0)), mine,
                             float(st.get("device_posting_visits", st.get("posting_visits", 0)))], dtype=torch.float64, device=self.comm)
         if self.world > 1:
@@ -304,13 +439,16 @@ class ShardedJoin:
         self.last = {
             "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
             "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
-            "head_terms": int(self.head.size), "head_int8": st.get("head_int8", 0),
+            "head_terms": int(self.head.size) if self.T > 1 else st.get("head_terms", 0), "head_int8": st.get("head_int8", 0),
             "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()), "device_posting_visits": int(tot[3].item()),
-            "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes,
-                         "union": int(uniq.numel()), "all_gather_bytes_per_rank": 8 * max(sizes + [1]) * self.T,
-                         "all_reduce_bytes": 4 * int(uniq.numel()), "term_ranges": self.ranges,
-                         "tail_terms_per_row_and_shard": self.tail_terms_per_row_and_shard},
+            "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes_all,
+                         "union": union_all,
+                         "all_gather_bytes_per_rank": 8 * max(sizes_all + [1]) * self.T if self.T > 1 else 0,
+                         "all_reduce_bytes": 4 * union_all if self.T > 1 else 0, "term_ranges": self.ranges,
+                         "tail_terms_per_row_and_shard": self.tail_terms_per_row_and_shard,
+                         "symmetric_row_ranges": bool(self.D > 1 and len(phases) > 1)},
         }
         if return_pairs:  # this rank's group result (the whole result when D == 1)
-            return uq[keep].cpu().numpy(), uc[keep].cpu().numpy(), part[keep].cpu().numpy()
+            cat = lambda xs, dt: torch.cat(xs) if xs else torch.zeros(0, dtype=dt, device=self.device)  # noqa: E731
+            return (cat(out_q, torch.int64).cpu().numpy(), cat(out_c, torch.int64).cpu().numpy(), cat(out_s, torch.float32).cpu().numpy())
         return int(tot[2].item())

@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--term-shards", type=int, default=None, help="T of the T x D rank grid of the headline layout (default: all ranks)")
     ap.add_argument("--solo", default=None, help="T,D,i,j: time shard (term i of T, rows j of D) alone on this GPU (projection)")
     ap.add_argument("--no-comparison-row", action="store_true", help="skip the candidate-range layout of multi-GPU runs")
+    ap.add_argument("--no-symmetric-ranges", action="store_true", help="D > 1: every cell meets every row as a query (round 3's scheme) "
+                                                                         "instead of half of the other ranges with mirrored pairs")
     ap.add_argument("--deadline", type=float, default=900.0, help="seconds before the watchdog ends a stalled run (exit 3)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real run) | gloo (rehearsal: all ranks share GPU 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget of the baseline sample")
@@ -345,7 +347,7 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
     def timed(T, label):
         wd.phase = label
         sj = ShardedJoin(cfg["dim"], cfg["theta"], rank, world, dev, tile_rows=a.tile_rows, comm_device=comm_dev, term_shards=T,
-                         head_terms=a.head_terms)
+                         head_terms=a.head_terms, symmetric_ranges=not a.no_symmetric_ranges)
         sj.load(rp, idx, val)
         probe_ms, build_ms, head_ms = [], [], []
         for _ in range(a.warmup):
@@ -611,8 +613,14 @@ def main():
                 df[terms] = 0
         tr = term_ranges(df, T)[ti]
         eng = HipShardEngine(cfg["dim"], cfg["theta"], tr, dev, a.tile_rows, head)
-        eng.load(rp, idx, val, None if D == 1 else (n * dj // D, n * (dj + 1) // D))
-        step = eng.join if T == 1 else (lambda: int(eng.candidates()[0].numel()))  # term shards hand their candidates on
+        spans = None
+        if D > 1 and not a.no_symmetric_ranges:  # the rows this cell owns the cross pairs with (apss.dist.ShardedJoin.half_spans)
+            from apss.dist import half_spans
+            spans = half_spans(n, D, dj)
+        eng.load(rp, idx, val, None if D == 1 else (n * dj // D, n * (dj + 1) // D), query_spans=spans)
+
+        def step():  # one step of the cell: every phase's handle call (term shards hand their candidates on)
+            return sum(int(eng.run_phase(ph)) for ph in eng.phases())
         step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -13,7 +13,7 @@ class OracleShardEngine:
         self.head = head
         self.stats = {}
 
-    def load(self, rp, idx, val, row_range=None):
+    def load(self, rp, idx, val, row_range=None, query_spans=None):
         import scipy.sparse as sp
         n = len(rp) - 1
         x = sp.csr_matrix((val, idx, rp), shape=(n, self.dim), dtype=np.float64)
@@ -32,12 +32,38 @@ class OracleShardEngine:
         self.sub = np.sqrt(np.asarray(self.xt.multiply(self.xt).sum(axis=1)).ravel())
         self.n = n
         self.r0, self.r1 = (0, n) if row_range is None else row_range
+        # the symmetric scheme across row ranges (apss.dist.HipShardEngine.load): own rows x own rows, then only the rows of
+        # `query_spans` as an outside batch whose pairs the caller mirrors
+        self.sym = row_range is not None and query_spans is not None
+        self.o_rows = np.concatenate([np.arange(a, b) for a, b in query_spans] + [np.zeros(0, np.int64)]).astype(np.int64) if self.sym else None
 
-    def candidates(self):
-        g = (self.xt @ self.xt[self.r0:self.r1].T).tocoo()  # queries: all rows; candidates: this shard's rows
+    def phases(self):
+        return ("own", "outside") if self.sym else ("all",)
+
+    def run_phase(self, phase):
+        rows = {"own": np.arange(self.r0, self.r1), "outside": self.o_rows, "all": np.arange(self.n)}[phase]
+        first = phase in ("own", "all")
+        prev = dict(self.stats) if not first else {"posting_visits": 0, "candidate_pairs": 0}
+        self._pairs = self.candidates(rows)
+        self.stats = {"posting_visits": 0, "candidate_pairs": prev["candidate_pairs"] + (2 if phase == "outside" else 1) * self.stats["candidate_pairs"]}
+        return int(self._pairs[0].numel())
+
+    def phase_pairs(self, n):
+        return self._pairs
+
+    def phase_partial(self, q, c):
+        return self.partial(q, c)
+
+    def candidates(self, query_rows=None):
+        qr = np.arange(self.n) if query_rows is None else np.asarray(query_rows, np.int64)
+        if qr.size == 0:
+            self.stats = {"posting_visits": 0, "candidate_pairs": 0}
+            return torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64)
+        g = (self.xt[qr] @ self.xt[self.r0:self.r1].T).tocoo()  # queries: the given rows (default all); candidates: this shard's rows
         col = g.col + self.r0
-        off = g.row != col
-        r, c, v = g.row[off], col[off], g.data[off]
+        grow = qr[g.row]
+        off = grow != col
+        r, c, v = grow[off], col[off], g.data[off]
         # p_g >= theta |q_g||c_g| / (|q||c|)
         keep = v * self.full[r] * self.full[c] >= self.theta * self.sub[r] * self.sub[c] * 0.999999
         self.stats = {"posting_visits": 0, "candidate_pairs": int(off.sum())}
@@ -45,11 +71,12 @@ class OracleShardEngine:
         if self.w is not None:
             rows = np.arange(self.r0, self.r1)
             mine = rows[((rows - self.r0) // 64) % self.head[2] == self.head[1]]  # this shard's candidate tiles (by slot)
-            gh = (self.w @ self.w[mine].T).tocoo()
+            gh = (self.w[qr] @ self.w[mine].T).tocoo()
             hc = mine[gh.col]
+            hr = qr[gh.row]
             bound = float(self.full.max()) ** 2
-            hk = (gh.row != hc) & (gh.data >= self.theta - 0.008 * bound)
-            r, c = np.concatenate([r, gh.row[hk]]), np.concatenate([c, hc[hk]])
+            hk = (hr != hc) & (gh.data >= self.theta - 0.008 * bound)
+            r, c = np.concatenate([r, hr[hk]]), np.concatenate([c, hc[hk]])
         return torch.from_numpy(r.astype(np.int64)), torch.from_numpy(c.astype(np.int64))
 
     def partial(self, q, c):

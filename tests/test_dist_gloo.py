@@ -45,7 +45,7 @@ def _worker(rank, world, port, out_dir, term_shards, head_k=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,term_shards,head_k", [(2, 2, 0), (3, 3, 0), (4, 2, 0), (2, 1, 0), (2, 2, 12), (4, 2, 12), (3, 3, 40)])
+@pytest.mark.parametrize("world,term_shards,head_k", [(2, 2, 0), (3, 3, 0), (4, 2, 0), (2, 1, 0), (3, 1, 0), (4, 1, 0), (2, 2, 12), (4, 2, 12), (3, 3, 40)])
 def test_sharded_join_matches_oracle(tmp_path, oracle, world, term_shards, head_k):
     """T term shards x D candidate ranges: union over the D groups == the oracle's result; inside a group every rank
     holds the identical group result (all-reduced partial scores).  head_k > 0: the join's dense-head block -- rank 0's
@@ -60,14 +60,23 @@ def test_sharded_join_matches_oracle(tmp_path, oracle, world, term_shards, head_
     want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
     assert len(want) > 50
     T, D = term_shards, world // term_shards
-    got_all = {}
+    got_all, seen_cross = {}, set()
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         got = to_map(z["q"], z["c"], z["s"])
         r0, r1 = int(z["r0"]), int(z["r1"])
-        assert all(r0 <= c < r1 for (_, c) in got)  # a group reports candidates of its own row range only
-        sub = {k: v for k, v in want.items() if r0 <= k[1] < r1}
-        assert_same_pairs(got, sub, theta, band=1e-5, tol=1e-5)
+        assert len(got) == z["q"].size  # no pair twice inside a group's answer
+        if D == 1:
+            assert_same_pairs(got, want, theta, band=1e-5, tol=1e-5)
+        else:
+            # symmetric scheme across the D row ranges (apss.dist.ShardedJoin.half_spans): a group reports the pairs inside its
+            # own range and, IN BOTH DIRECTIONS, the cross pairs it owns -- every pair touches its range, none is reported by two
+            # groups, and all are the oracle's
+            assert all(r0 <= q < r1 or r0 <= c < r1 for (q, c) in got)
+            assert all(k in want or abs(v - theta) <= 1e-5 for k, v in got.items())
+            if r % T == 0:
+                assert not (set(got) & seen_cross), "a pair was reported by two groups"
+                seen_cross |= set(got)
         assert int(z["total"]) == len(want) or abs(int(z["total"]) - len(want)) <= 2  # whole-job count on every rank
         got_all.update(got)
         if r % T == 0:

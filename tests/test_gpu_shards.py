@@ -236,3 +236,55 @@ def test_signed_weights_under_the_shard_rule(oracle):
     # (a shard's survivors are its candidates; what shows the filter ran instead of the general kernel is its time:
     # profiles/r02_summary.md, "signed weights under the shard rule")
     assert sum(e.stats["posting_visits"] for e in engines) == int((np.bincount(idx, minlength=dim).astype(np.int64) ** 2).sum())
+
+
+@pytest.mark.parametrize("T,D,head", [(1, 2, None), (1, 3, None), (1, 4, None), (2, 4, 64), (2, 3, None)])
+def test_symmetry_across_row_ranges(oracle, T, D, head):
+    """the T x D grid with the symmetry used ACROSS the row ranges (apss.dist.ShardedJoin.half_spans, round 4): a cell joins its
+    own rows with themselves and meets only the rows of the ranges it owns the cross pairs with; the pairs it finds there are
+    reported in both directions.  Union over the grid == the oracle's list, no pair from two cells, and the devices make about
+    half of the cross-range posting visits.  Cells built one after another on one GPU, exchange in-process as apss.dist does it"""
+    import torch
+    from apss.dist import HipShardEngine, half_spans, term_ranges
+    n, dim, nnz, theta = 6000, 3000, 30, 0.55
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 1.0 if head else 0.0, seed=140 + 7 * D + T, dup_frac=0.1)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 200
+    dev = torch.device("cuda", 0)
+    df = np.bincount(idx, minlength=dim)
+    head_terms = None
+    if head:
+        head_terms = np.lexsort((np.arange(dim), -df))[:head].astype(np.int32)
+        df = df.copy()
+        df[head_terms] = 0
+    ranges = term_ranges(df, T)
+    got, dev_visits, ref_visits = {}, 0, 0
+    for dj in range(D):
+        spans = half_spans(n, D, dj)
+        r0, r1 = n * dj // D, n * (dj + 1) // D
+        engines = [HipShardEngine(dim, theta, ranges[i], dev, tile_rows=512, head=None if head_terms is None else (head_terms, i, T, 0))
+                   for i in range(T)]
+        for e in engines:
+            e.load(rp, idx, val, (r0, r1), query_spans=spans)
+        for ph in engines[0].phases():
+            keys = []
+            for e in engines:
+                q, c = e.phase_pairs(e.run_phase(ph))
+                keys.append(q * n + c)
+            uniq = torch.unique(torch.cat(keys))
+            uq, uc = torch.div(uniq, n, rounding_mode="floor"), uniq % n
+            total = sum(e.phase_partial(uq, uc) for e in engines)
+            keep = total >= theta
+            cell = to_map(uq[keep].cpu().numpy(), uc[keep].cpu().numpy(), total[keep].cpu().numpy())
+            if ph == "outside":
+                assert all(r0 <= c < r1 and not (r0 <= q < r1) for (q, c) in cell)
+                cell.update({(c, q): v for (q, c), v in list(cell.items())})
+            assert not (set(cell) & set(got)), "a pair from two cells"
+            got.update(cell)
+        dev_visits += sum(e.stats["device_posting_visits"] for e in engines)
+        ref_visits += sum(e.stats["posting_visits"] for e in engines)
+    assert_same_pairs(got, want, theta)
+    full = int((np.bincount(idx, minlength=dim).astype(np.int64) ** 2).sum()) if head_terms is None else None
+    if full is not None:
+        assert ref_visits == full  # reference-equivalent count: every (query, term, posting) of the two-directional join
+        assert dev_visits < 0.75 * full  # the devices made about half of them (small tiles: the diagonal's share is visible)
