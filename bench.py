@@ -113,7 +113,10 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
         s_all = sample  # (the same sample: a GPU box may expose every core of the machine while the run is entitled to a share of them)
         ra = oracle.selfjoin_sample(0, cfg["dim"], cfg["theta"], rp, idx, val, 0, s_all, avail)
         all_cores = {"value": ra["cand_pairs"] / ra["seconds"], "cores": avail,
-                     "sample": "first %d queries, %.1f s, %d threads" % (s_all, ra["seconds"], avail)}
+                     "sample": "first %d queries, %.1f s, %d threads" % (s_all, ra["seconds"], avail),
+                     "note": "memory-bound: every thread walks the same posting lists and a per-thread candidate stamp array of N "
+                             "entries; beyond a socket's worth of threads the port does not scale (it may be SLOWER than the headline "
+                             "row's %d threads) -- a stated baseline, not a tuned one" % cores}
     return {
         "value": r["cand_pairs"] / r["seconds"], "unit": "scored candidate pairs/s", "cores": cores, "kind": "port",
         "sample": "all %d vectors indexed, first %d queries timed (%.1f s, %d threads: queries split by range, every "
@@ -131,11 +134,11 @@ def cpu_baseline(cfg, rp, idx, val, budget_s):
     }
 
 
-PROBE_TRAFFIC = os.path.join(ROOT, "profiles", "r03_probe_traffic.json")
+PROBE_TRAFFIC = os.path.join(ROOT, "profiles", "r04_probe_traffic.json")
 
 
 def csrc_sha256():
-    """content hash of the library's sources (what profiles/collect_r03.sh records beside the counters it collects)"""
+    """content hash of the library's sources (what profiles/collect_r04.sh records beside the counters it collects)"""
     import glob
     import hashlib
     csrc = os.path.join(ROOT, "all-pairs-similarity_amd", "csrc")
@@ -147,7 +150,7 @@ def csrc_sha256():
 
 def profile_quote(workload, n_override, tile_rows, alg_bytes, kernel):
     """HBM-side bytes and SQ counters of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the
-    committed summary of the same command (profiles/collect_r03.sh -> profiles/r03_probe_traffic.json) is quoted -- only
+    committed summary of the same command (profiles/collect_r04.sh -> profiles/r04_probe_traffic.json) is quoted -- only
     when the workload matches byte for byte AND the kernel that ran here (apss_stats.probe_kernel) is the kernel the
     counters were collected on; anything else is refused (traffic: null), never quoted from another kernel."""
     if n_override or tile_rows or not os.path.exists(PROBE_TRAFFIC):
@@ -255,7 +258,7 @@ def single_gpu(a, cfg, rp, idx, val, d_arrays, dev, local_rank, sync, wd):
             "measured_frac": traffic / (probe_s / launches) / 1e9 / HBM_PEAK_GBS,
             "measured_frac_of_copy_peak": traffic / (probe_s / launches) / 1e9 / HBM_COPY_GBS,
             "traffic_note": "bytes per launch at the L2 <-> fabric boundary, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate "
-                            "rocprofv3 --pmc passes of this command (profiles/r03_probe_traffic.json); gfx950 tallies 128-B read "
+                            "rocprofv3 --pmc passes of this command (profiles/r04_probe_traffic.json); gfx950 tallies 128-B read "
                             "requests at 64 B; Infinity-Cache hits are included, HBM itself sees each posting once per step",
             "lds_issue_frac": quote.get("lds_issue_frac"), "valu_busy_frac": quote.get("valu_busy_frac"),
             "counted_on": quote["counted_on"],

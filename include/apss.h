@@ -75,8 +75,8 @@ typedef struct apss_config {
   int32_t head_terms;      /* dense-head block: 0 = the library decides from the term distribution, -1 = never,
                               N <= 32768 = always the N most frequent terms.  Up to 256 terms: a column each.  More: ONE block of
                               256 columns, the 128 most frequent terms with a column each, the others FOLDED into the other 128
-                              (several terms add into one column: an upper bound of their partial score for non-negative
-                              weights).  Terms in the block are scored by an MFMA contraction instead of their posting lists --
+                              (a shared column holds the L2 norm of its terms: by Cauchy-Schwarz an upper bound of their partial
+                              score that keeps the row's norm).  Terms in the block are scored by an MFMA contraction instead of their posting lists --
                               over INT8 rows rounded UP (a sound filter: integer products, int32 sums) or bf16 rows
                               (apss_stats.head_int8); survivors are re-scored exactly: results are the same set */
   int64_t capacity_rows;   /* hints for the initial HBM reservation (0 = grow on demand) */
@@ -212,7 +212,7 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
 
 
 /* ---- dense-head block set by the caller ----
- * The `n_terms` (<= 32768; more than 256: the first 128 with a column each, the others folded, in the order given) most frequent terms are scored by a bf16 MFMA contraction over W = [rows x n_terms] instead of
+ * The `n_terms` (<= 32768; more than 256: the first 128 with a column each, the others folded, in the order given) most frequent terms are scored by an MFMA contraction (INT8 rows rounded up, or bf16: apss_stats.head_int8) over W = [rows x n_terms] instead of
  * their posting lists (CommonUtils.scala:110-115 restricted to those dims; a FILTER: survivors are re-scored exactly).
  * On a plain handle this replaces the library's own choice (apss_config.head_terms).  On a TERM SHARD it is the only way
  * to get a block: every shard of a join must be given the SAME terms -- they are a part of their own, {H, T_1 .. T_T}, in
@@ -225,7 +225,7 @@ int32_t apss_partial_scores_dev(apss_handle *h, int64_t n_pairs, const int32_t *
  * APSS_FLAG_ADMISSION (APSS_E_UNSUPPORTED otherwise). */
 int32_t apss_set_head_terms(apss_handle *h, int32_t n_terms, const int32_t *terms, int32_t part, int32_t n_parts);
 /* How many of the 256 columns of a head of more than 256 terms are FOLDED columns (64 | 128 | 192; 0 = the default, 128):
- * the 256 - columns most frequent terms keep a column each, the others add into the folded ones.  Takes effect at the next
+ * the 256 - columns most frequent terms keep a column each, the others share the folded ones (L2 norm per column).  Takes effect at the next
  * apss_set_head_terms; on an empty handle. */
 int32_t apss_set_head_fold(apss_handle *h, int32_t columns);
 /* the block's terms in block order (chosen by the library or set by the caller); *n_terms = how many there are */
