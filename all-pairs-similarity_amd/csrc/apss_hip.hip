@@ -984,8 +984,13 @@ int32_t choose_head(apss_handle *h, bool *changed) {
       s2_all += f * f;
       f_max = std::max(f_max, f);
     }
-    const double s2_bound = std::min(s2_all, (double)top * f_max * f_max);
-    hopeless = s2_bound / kHeadSparseRate < 1.5 * 0.5 * (head_wants_i8(h) ? kHeadDenseCostI8 : kHeadDenseCost)[0];
+    // (per block size: k terms save at most min(all terms', k x the most frequent one's) visits against THAT block's cost -- a
+    // single comparison with the cheapest block's cost stopped holding on C3 when the INT8 rendering made that block cheaper)
+    const double *cost = head_wants_i8(h) ? kHeadDenseCostI8 : kHeadDenseCost;
+    const double terms_of[4] = {64.0, 128.0, 256.0, (double)top};
+    hopeless = true;
+    for (int ki = 0; ki < 4; ++ki)
+      if (std::min(s2_all, terms_of[ki] * f_max * f_max) / kHeadSparseRate >= 1.5 * 0.5 * cost[ki]) hopeless = false;
   }
   if (!hopeless) {
     std::nth_element(order.begin(), order.begin() + (ptrdiff_t)top - 1, order.end(), more_frequent);

@@ -391,20 +391,37 @@ __global__ __launch_bounds__(1024) void k_tile_scan_part(const uint2 *tile_seg, 
   uint32_t total;
   (void)block_excl_scan_1024<uint32_t>(s, wave_tot, &total);
   if (tid == 0) part[blockIdx.x] = total;
-  // the longest (tile, term) segment of the build: tells the probe whether its long-segment machinery is needed at all
+  // the longest (tile, term) segment of the build: tells the probe whether its long-segment machinery is needed at all.
+  // Combined per workgroup first (LDS), then ONE global atomic each per workgroup: same-address global atomics are serialised
+  // at the memory side (a wave-level atomic per statistic made this kernel 215 us over 31 tiles x 25 blocks)
+  __shared__ uint32_t sh_long[2];
+  __shared__ unsigned long long sh_cw;
+  if (tid == 0) {
+    sh_long[0] = sh_long[1] = 0u;
+    sh_cw = 0ull;
+  }
+  __syncthreads();
   for (int o = kWave / 2; o; o >>= 1) {
     longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
     n_long += (uint32_t)__shfl_xor((int)n_long, o);
-  }
-  if (max_len && (tid % kWave) == 0 && longest) {
-    atomicMax(max_len, longest);
-    if (n_long && count_long) atomicAdd(max_len + 1, n_long);  // [1]: long segments over all tiles of the build (an appended-to tile was counted before)
   }
   // A row of the tile holds term t with probability len_t / rows, and a query holding t meets ceil(len_t / 16) chunks of this
   // tile: sum_t len_t * ceil(len_t / 16) / rows = the chunks an average round (a query distributed like the tile's rows) deals
   // out, whatever the term distribution -- what the probe sizes its register window from
   for (int o = kWave / 2; o; o >>= 1) cw += __shfl_xor(cw, o);
-  if (chunk_w && (tid % kWave) == 0 && cw) atomicAdd(chunk_w, cw);
+  if ((tid % kWave) == 0) {
+    if (longest) atomicMax(&sh_long[0], longest);
+    if (n_long) atomicAdd(&sh_long[1], n_long);
+    if (cw) atomicAdd(&sh_cw, cw);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (max_len && sh_long[0]) {
+      atomicMax(max_len, sh_long[0]);
+      if (sh_long[1] && count_long) atomicAdd(max_len + 1, sh_long[1]);  // [1]: long segments over all tiles of the build (an appended-to tile was counted before)
+    }
+    if (chunk_w && sh_cw) atomicAdd(chunk_w, sh_cw);
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_tile_scan_place(uint2 *tile_seg, int64_t seg_stride, int32_t dim, int64_t tile0, int32_t n_blk,
