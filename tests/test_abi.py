@@ -71,6 +71,17 @@ def test_no_cpu_fallback(so):
     assert e.value.code == _lib.E_DEVICE
 
 
+def test_group_needs_a_gpu_too(so):
+    """apss_group_create without a device: APSS_E_DEVICE and a message, never a CPU path"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from apss.engine import ApssError, ApssGroup
+    with pytest.raises(ApssError) as e:
+        ApssGroup(16, 0.5, [0, 1])
+    assert e.value.code == _lib.E_DEVICE and "no usable HIP device" in str(e.value)
+
+
 def test_product_never_imports_oracle():
     """the product path must not import, link or load anything under oracle/ (mentions in prose are fine)"""
     pkg = os.path.join(ROOT, "all-pairs-similarity_amd")
