@@ -701,8 +701,8 @@ double acc8_scale(double bound, double shared, double theta) {
 }
 
 // ---- dense-head block (apss_head.hpp) ----
-constexpr int64_t kTailMaxRows = 4096;   // rows that may wait outside the tile index (scored pair by pair by k_tail_score)
-constexpr int64_t kTailMaxBatch = 256;   // a batch larger than this extends the index right away
+constexpr int64_t kTailMaxRows = 1024;   // rows that may wait outside the tile index (scored pair by pair by k_tail_score; 4096 until the append build made folding them in cheap)
+constexpr int64_t kTailMaxBatch = 64;    // a batch larger than this extends the index right away (256 until the append build)
 constexpr int64_t kTailMaxPairs = 1 << 22;  // (queries x tail rows) a probe scores directly; beyond it the tail is folded in first
 constexpr int32_t kHeadMaxTerms = kHeadBlock * (1 + kHeadMaxFold);   // 256 terms with a column each + 256 columns of kHeadMaxFold terms
 // width of a W row holding n_terms head terms: one block of 64 | 128 | 256 columns, or 256 + a folded block of fold_w columns

@@ -250,3 +250,28 @@ def test_group_ingest_flags(oracle):
     with _group(dim, theta, 3, flags=_lib.FLAG_NORMALIZE | _lib.FLAG_VALUE_PRUNE, index_threshold=thr, head_terms=-1) as g:
         got = to_map(*g.insert_and_query(np.arange(n), rp, idx, raw))
     assert_same_pairs(got, want, theta, band=2e-5, tol=2e-5)
+
+
+def test_group_admission_filter_drops_the_same_rows_on_every_member(oracle):
+    """APSS_FLAG_ADMISSION (EntryProxyActor.scala:81-93: a vector is admitted iff sum_i v_i >= theta) is a decision about the
+    WHOLE row, which every member is handed: the members drop the same rows, slots stay aligned across them, and the group's
+    answer (external ids through member 0's arrays) equals the oracle worker's on the admitted rows"""
+    n, dim, nnz, theta = 4000, 1200, 12, 0.6
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=23, dup_frac=0.4)
+    rng = np.random.default_rng(5)
+    val = val * np.repeat(rng.uniform(0.12, 1.0, size=n), nnz)  # un-normalised: the row sums straddle theta
+    keep = oracle.admission(rp, val, theta)
+    assert 0.2 * n < keep.sum() < 0.95 * n
+    rows = np.nonzero(keep)[0]
+    krp = np.concatenate([[0], np.cumsum((rp[1:] - rp[:-1])[rows])]).astype(np.int64)
+    sel = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])
+    ids = np.arange(n, dtype=np.int64) + 50
+    w = oracle.Worker(dim, theta)
+    want = to_map(*w.index_data(ids[rows], krp, idx[sel], val[sel]))
+    assert len(want) > 20
+    with _group(dim, theta, 3, flags=_lib.FLAG_ADMISSION, head_terms=0) as g:
+        got = to_map(*g.insert_and_query(ids, rp, idx, val))
+        st = g.stats()
+        assert st["rows"] == int(keep.sum()) and st["head_terms"] == 0
+        assert all(g.member_stats(i)["rows"] == st["rows"] for i in range(3))
+    assert_same_pairs(got, want, theta, band=2e-5, tol=2e-5)
