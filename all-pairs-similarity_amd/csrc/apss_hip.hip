@@ -60,6 +60,8 @@ struct DebugCfg {
   int mix = 0;                 // mix=E          ONE head block of 256 columns: E terms with a column each, the others folded into 256 - E
   bool no_chain = false;       // no_chain       small batches take the exact pass with its own host round trips (as large ones do)
   bool no_append = false;      // no_append      a batch that lands in a partly filled tile rebuilds the whole tile (never appends to it)
+  bool no_bucket = false;      // no_bucket      large dims build with global atomics (never the bucketed LDS build)
+  int bucket_range = 0;        // bucket_range=N terms per range of the bucketed LDS build (a power of two <= 16384; default 2048)
   int res_cap = 0;             // res_cap=N      initial capacity of the candidate list (tests of the overflow -> regrow -> re-run path)
   bool head_bf16 = false;      // head_bf16      the dense-head block keeps bf16 rows (v_mfma_f32_32x32x16_bf16), never the INT8 rendering
 };
@@ -105,6 +107,8 @@ DebugCfg parse_debug_env() {
     else if (key == "no_append") d.no_append = val != 0;
     else if (key == "head_bf16") d.head_bf16 = val != 0;
     else if (key == "res_cap") d.res_cap = val;
+    else if (key == "no_bucket") d.no_bucket = val != 0;
+    else if (key == "bucket_range") d.bucket_range = val;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -175,6 +179,11 @@ struct apss_handle {
   DevBuf<int32_t> in_idx;
   DevBuf<float> s_inv, s_sub, in_val;
   DevBuf<double> in_val64;
+  DevBuf<unsigned long long> bk_cnt;  // bucketed LDS build (large dims): entries per (tile, term range) + cursors,
+  DevBuf<int64_t> bk_base;            //   their exclusive scan,
+  DevBuf<int32_t> bk_idx;             //   and the entries partitioned by (tile, range): term, store row, value
+  DevBuf<uint32_t> bk_erow;
+  DevBuf<float> bk_val;
   DevBuf<uint2> app_seg;             // append build: the last tile's segment table and postings before the append
   DevBuf<char> app_post;
   DevBuf<int32_t> vq_first, vrow_q;  // virtual-row table of the last query batch (queries of > 512 terms)
@@ -618,11 +627,22 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   ix.h_base.resize((size_t)tile0 + 1);  // bases of the tiles that stay
   const int64_t r0 = tile0 * cb;
   // small dims: counters and cursors of a (tile, term range) live in one workgroup's LDS (no global atomics)
-  const int32_t n_ranges = (int32_t)ceil_div(h->cfg.dim, kBuildRange);
+  int32_t n_ranges = (int32_t)ceil_div(h->cfg.dim, kBuildRange);
   // (one workgroup per (tile, range): with fewer than ~48 of them -- a small batch, a rebuilt tail tile, a 1/8 candidate
   // range -- the row-parallel global-atomic kernels are faster; APSS_BUILD_LDS / APSS_BUILD_ATOMIC force either)
-  const bool lds_build = n_ranges <= kBuildMaxRanges && !h->dbgcfg.build_atomic &&
-                         ((n_tiles - tile0) * n_ranges >= 48 || h->dbgcfg.build_lds);
+  // large dims (more than kBuildMaxRanges ranges: vectorDim = 2^20): a build from the first tile partitions the entries by
+  // term range first (k_bucket_pass), so that the LDS build's workgroups read their bucket instead of the whole tile
+  const int64_t build_nnz = h->head_k ? h->tv.nnz : h->nnz;  // entries of the rows [0, idx_rows) the index is built from
+  // (terms per range of a bucketed build, measured on C5's shape, build ms per step: 1024: 28.3, 2048: 23.9, 4096: 20.4, 8192: 15.6,
+  // 16384: 17.4 -- against 37.5 with the global-atomic kernels; narrow ranges multiply the workgroups' fixed work)
+  int32_t bucket_rt = h->dbgcfg.bucket_range > 0 ? h->dbgcfg.bucket_range : 8192;
+  while (ceil_div(h->cfg.dim, bucket_rt) > kBucketMaxRanges && bucket_rt < kBuildRange) bucket_rt *= 2;
+  const bool bucket_build = n_ranges > kBuildMaxRanges && ceil_div(h->cfg.dim, bucket_rt) <= kBucketMaxRanges && !h->dbgcfg.build_atomic &&
+                            !h->dbgcfg.no_bucket && tile0 == 0 && n_tiles * n_ranges >= 48 && build_nnz > 0 && build_nnz <= (1LL << 32) &&
+                            n_tiles * (int64_t)kBucketSlices < (1LL << 31);
+  if (bucket_build) n_ranges = (int32_t)ceil_div(h->cfg.dim, bucket_rt);
+  const bool lds_build = bucket_build || (n_ranges <= kBuildMaxRanges && !h->dbgcfg.build_atomic &&
+                                          ((n_tiles - tile0) * n_ranges >= 48 || h->dbgcfg.build_lds));
   if (!lds_build)
     HIPCHK(h, hipMemsetAsync(ix.seg.p + tile0 * stride, 0, (size_t)((n_tiles - tile0) * stride) * sizeof(uint2), h->stream));
   BuildArgs b{};
@@ -632,6 +652,41 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   const int threads = 256;
   const int64_t blocks = ceil_div((h->idx_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  if (bucket_build) {
+    const int64_t nb = n_tiles * n_ranges;
+    APSS_TRY(ensure(h, h->bk_cnt, (size_t)(2 * nb + 2)));
+    APSS_TRY(ensure(h, h->bk_base, (size_t)nb + 2));
+    APSS_TRY(ensure(h, h->bk_idx, (size_t)build_nnz));
+    APSS_TRY(ensure(h, h->bk_erow, (size_t)build_nnz));
+    APSS_TRY(ensure(h, h->bk_val, (size_t)build_nnz));
+    HIPCHK(h, hipMemsetAsync(h->bk_cnt.p, 0, (size_t)(2 * nb + 2) * sizeof(unsigned long long), h->stream));
+    BucketArgs k{};
+    k.rowptr = b.rowptr;
+    k.idx = b.idx;
+    k.val = b.val;
+    k.erow = b.erow;
+    k.row1 = h->idx_rows;
+    k.cb = (int32_t)cb;
+    k.n_ranges = n_ranges;
+    k.range_terms = bucket_rt;
+    k.tile0 = 0;
+    k.bucket_cnt = h->bk_cnt.p;
+    k.bucket_cur = h->bk_cnt.p + nb + 1;
+    k.bucket_base = h->bk_base.p;
+    k.o_idx = h->bk_idx.p;
+    k.o_erow = h->bk_erow.p;
+    k.o_val = h->bk_val.p;
+    const dim3 bgrid((unsigned)(n_tiles * kBucketSlices));
+    hipLaunchKernelGGL(k_bucket_pass<false>, bgrid, dim3(1024), 0, h->stream, k);
+    APSS_TRY(scan_i64(h, reinterpret_cast<const int64_t *>(h->bk_cnt.p), h->bk_base.p, nb));
+    hipLaunchKernelGGL(k_bucket_pass<true>, bgrid, dim3(1024), 0, h->stream, k);
+    HIPCHK(h, hipGetLastError());
+    b.idx = h->bk_idx.p;
+    b.erow = h->bk_erow.p;
+    b.val = h->bk_val.p;
+    b.ent_base = h->bk_base.p;
+    b.range_terms = bucket_rt;
+  }
   const dim3 lds_grid((unsigned)((n_tiles - tile0) * n_ranges));
   if (lds_build) hipLaunchKernelGGL(k_tile_hist_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
   else hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
@@ -2388,7 +2443,7 @@ void apss_destroy(apss_handle *h) {
   release(h->head_pos); release(h->W);
   for (apss_handle::TailView *v : {&h->tv, &h->qtv}) { release(v->rowptr); release(v->idx); release(v->val); release(v->erow); }
   release(h->tv_cnt); release(h->tv_off); release(h->tv_sum); release(h->q_W); release(h->df); release(h->dedup_tab);
-  release(h->head_ctr); release(h->uq_q); release(h->uq_c); release(h->uq_s); release(h->pack); release(h->chain_ctr); release(h->app_seg); release(h->app_post);
+  release(h->head_ctr); release(h->uq_q); release(h->uq_c); release(h->uq_s); release(h->pack); release(h->chain_ctr); release(h->app_seg); release(h->app_post); release(h->bk_cnt); release(h->bk_base); release(h->bk_idx); release(h->bk_erow); release(h->bk_val);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -349,6 +349,11 @@ struct BuildArgs {
   const uint32_t *erow;           // store row of every entry (LDS build)
   const float *row_scale;         // shard rule (coarse rendering): row r's weights are stored divided by row_scale[r] = |x_g| / |x|,
                                   //   so that the filter's threshold does not depend on the candidate (null: as they are)
+  int32_t range_terms;            // terms per range of the LDS build's (tile, range) workgroups: 0 = kBuildRange; the bucketed build
+                                  //   of large dims names its own (8192: measured)
+  const int64_t *ent_base;        // LDS build over BUCKETED entries (dims of more than kBuildMaxRanges ranges): workgroup w = (tile, range)
+                                  //   reads entries [ent_base[w], ent_base[w + 1]) of idx / erow / val, which then point at the
+                                  //   bucketed copies (k_bucket_scatter); null: the tile's entries as they lie in the store
 };
 
 // one wave per row: coalesced reads of the row's entries
@@ -527,12 +532,13 @@ __global__ __launch_bounds__(1024) void k_tile_hist_lds(BuildArgs a, int64_t til
   __shared__ uint32_t cnt[kBuildRange];
   const int tid = threadIdx.x;
   const int64_t tile = tile0 + blockIdx.x / n_ranges;
-  const int32_t lo = (int32_t)(blockIdx.x % n_ranges) * kBuildRange;
-  const uint32_t span = (uint32_t)(min(a.dim, lo + kBuildRange) - lo);
-  for (int i = tid; i < kBuildRange; i += 1024) cnt[i] = 0u;
+  const int32_t rt = a.range_terms ? a.range_terms : kBuildRange;
+  const int32_t lo = (int32_t)(blockIdx.x % n_ranges) * rt;
+  const uint32_t span = (uint32_t)(min(a.dim, lo + rt) - lo);
+  for (int i = tid; i < rt; i += 1024) cnt[i] = 0u;
   __syncthreads();
   const int64_t rA = tile * a.cb, rB = min(a.row1, rA + (int64_t)a.cb);
-  const int64_t eA = a.rowptr[rA], eB = a.rowptr[rB];
+  const int64_t eA = a.ent_base ? a.ent_base[blockIdx.x] : a.rowptr[rA], eB = a.ent_base ? a.ent_base[blockIdx.x + 1] : a.rowptr[rB];
   for (int64_t k = eA + tid; k < eB; k += 4096) {  // four loads in flight per thread
     int32_t t[4];
 #pragma unroll
@@ -550,14 +556,15 @@ __global__ __launch_bounds__(1024) void k_tile_scatter_lds(BuildArgs a, int64_t 
   __shared__ uint32_t cur[kBuildRange];
   const int tid = threadIdx.x;
   const int64_t tile = tile0 + blockIdx.x / n_ranges;
-  const int32_t lo = (int32_t)(blockIdx.x % n_ranges) * kBuildRange;
-  const uint32_t span = (uint32_t)(min(a.dim, lo + kBuildRange) - lo);
+  const int32_t rt = a.range_terms ? a.range_terms : kBuildRange;
+  const int32_t lo = (int32_t)(blockIdx.x % n_ranges) * rt;
+  const uint32_t span = (uint32_t)(min(a.dim, lo + rt) - lo);
   const uint2 *sg = a.tile_seg + tile * a.seg_stride + lo;
   for (uint32_t i = tid; i < span; i += 1024) cur[i] = sg[i].x;  // cursor = segment start: the atomic returns the position
   __syncthreads();
   const int64_t pbase = a.tile_post_base[tile];
   const int64_t rA = tile * a.cb, rB = min(a.row1, rA + (int64_t)a.cb);
-  const int64_t eA = a.rowptr[rA], eB = a.rowptr[rB];
+  const int64_t eA = a.ent_base ? a.ent_base[blockIdx.x] : a.rowptr[rA], eB = a.ent_base ? a.ent_base[blockIdx.x + 1] : a.rowptr[rB];
   // every entry's row and value are loaded with its term, matching or not: three times the read traffic of this pass
   // (it comes from the caches) instead of a second dependent memory round trip for the quarter that matches
   for (int64_t k = eA + tid; k < eB; k += 4096) {
@@ -592,6 +599,69 @@ __global__ __launch_bounds__(1024) void k_tile_scatter_lds(BuildArgs a, int64_t 
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BUCKETED entries for the LDS build of LARGE dims (more than kBuildMaxRanges ranges of kBuildRange terms: vectorDim = 2^20,
+// the reference's HashingTF default).  The LDS build re-reads a tile's entries once per term range -- 64 times at dim = 2^20
+// -- which is why such dims kept the global-atomic kernels (two atomics per posting: 39 of the 161 ms of a C5-shaped step,
+// 0.59 of configs[4]'s 13.9 s).  Here a tile's entries are first PARTITIONED by term range, a counting sort in two passes
+// over (tile, slice) workgroups: count per range in LDS, one global atomic per (workgroup, range) to reserve a run of the
+// range's bucket, scatter through LDS cursors.  The LDS build's workgroup (tile, range) then reads ITS bucket only
+// (BuildArgs::ent_base).  Order inside a bucket -- hence inside a posting segment -- is whatever the atomics give, as it
+// is with the atomic build.
+constexpr int kBucketSlices = 64;       // workgroups per tile
+constexpr int kBucketMaxRanges = 1024;  // dims up to 2^24
+struct BucketArgs {
+  const int64_t *rowptr;
+  const int32_t *idx;
+  const float *val;
+  const uint32_t *erow;
+  int64_t row1;          // rows of the build end here
+  int32_t cb, n_ranges, range_terms;
+  int64_t tile0;
+  unsigned long long *bucket_cnt;       // [tiles x n_ranges] entries per (tile, range)        (pass 1 out)
+  const int64_t *bucket_base;           // [tiles x n_ranges + 1] their exclusive scan          (pass 2 in)
+  unsigned long long *bucket_cur;       // [tiles x n_ranges] entries placed so far             (pass 2)
+  int32_t *o_idx;
+  uint32_t *o_erow;
+  float *o_val;
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(1024) void k_bucket_pass(BucketArgs a) {
+  __shared__ uint32_t cnt[kBucketMaxRanges];
+  __shared__ int64_t base[kBucketMaxRanges];
+  const int tid = threadIdx.x;
+  const int64_t tl = blockIdx.x / kBucketSlices;  // tile of the build (0-based)
+  const int sl = blockIdx.x % kBucketSlices;
+  const int64_t rA = (a.tile0 + tl) * a.cb, rB = min(a.row1, rA + (int64_t)a.cb);
+  const int64_t eA = a.rowptr[rA], eB = a.rowptr[rB];
+  const int64_t per = (eB - eA + kBucketSlices - 1) / kBucketSlices;
+  const int64_t k0 = eA + sl * per, k1 = min(eB, k0 + per);
+  for (int i = tid; i < a.n_ranges; i += 1024) cnt[i] = 0u;
+  __syncthreads();
+  for (int64_t k = k0 + tid; k < k1; k += 1024) atomicAdd(&cnt[(uint32_t)a.idx[k] / (uint32_t)a.range_terms], 1u);
+  __syncthreads();
+  unsigned long long *const dst = (SCATTER ? a.bucket_cur : a.bucket_cnt) + tl * a.n_ranges;
+  for (int i = tid; i < a.n_ranges; i += 1024) {
+    const uint32_t c = cnt[i];
+    if (c) {
+      const unsigned long long at = atomicAdd(&dst[i], (unsigned long long)c);  // (pass 2: the start of this workgroup's run)
+      if (SCATTER) base[i] = a.bucket_base[tl * a.n_ranges + i] + (int64_t)at;
+    }
+    if (SCATTER) cnt[i] = 0u;  // becomes the run's cursor
+  }
+  if (!SCATTER) return;
+  __syncthreads();
+  for (int64_t k = k0 + tid; k < k1; k += 1024) {
+    const int32_t t = a.idx[k];
+    const uint32_t r = (uint32_t)t / (uint32_t)a.range_terms;
+    const int64_t p = base[r] + atomicAdd(&cnt[r], 1u);
+    a.o_idx[p] = t;
+    a.o_erow[p] = a.erow[k];
+    a.o_val[p] = a.val[k];
   }
 }
 
