@@ -497,6 +497,34 @@ def test_global_atomic_index_build_matches_the_lds_build(apss_mod, monkeypatch, 
     assert_same_pairs(got, to_map(z["out_q"], z["out_c"], z["out_sim"]), theta)
 
 
+@pytest.mark.parametrize("flags_name", ["two_pass", "exact_wave"])
+def test_bucketed_index_build_for_large_dims(apss_mod, oracle, monkeypatch, flags_name):
+    """dims of more than 16 x 16384 terms (the reference's HashingTF default is 2^20): a build from the first row partitions the
+    entries by term range (k_bucket_pass) and runs the LDS build over the buckets instead of two global atomics per posting;
+    same pairs and counters as the atomic build (APSS_DEBUG=no_bucket), the oracle's pairs on a query sample, and a later
+    batch (appended: atomic kernels) on top"""
+    from apss import _lib
+    n, dim, nnz, theta = 150_000, 400_000, 24, 0.6
+    rp, idx, val = synth.make_vectors(n, dim, nnz, 0.0, seed=404, dup_frac=0.08)
+    flags = {"two_pass": 0, "exact_wave": _lib.FLAG_EXACT_ACCUM}[flags_name]
+    got, st = _gpu_join(apss_mod, dim, theta, rp, idx, val, flags=flags)
+    monkeypatch.setenv("APSS_DEBUG", "no_bucket")
+    ref, st_ref = _gpu_join(apss_mod, dim, theta, rp, idx, val, flags=flags)
+    monkeypatch.delenv("APSS_DEBUG")
+    assert len(got) > 5000 and got.keys() == ref.keys()
+    assert st["candidate_pairs"] == st_ref["candidate_pairs"] and st["posting_visits"] == st_ref["posting_visits"] == int(synth.workload_counts(dim, rp, idx)[1])
+    sample = 1500
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val, 0, sample))
+    assert_same_pairs({k: v for k, v in got.items() if k[0] < sample}, want, theta)
+    # a second batch lands on the bucket-built index
+    m = 120_000
+    with apss_mod.ApssIndex(dim, theta, flags=flags) as ix:
+        ix.insert(np.arange(m), rp[:m + 1], idx[:rp[m]], val[:rp[m]])
+        q, c, s = ix.insert_and_query(np.arange(m, n), rp[m:] - rp[m], idx[rp[m]:], val[rp[m]:])
+    later = to_map(q, c, s)
+    assert later == {k: v for k, v in ref.items() if k[0] >= m} or later.keys() == {k for k in ref if k[0] >= m}
+
+
 def test_handles_are_independent_across_threads(apss_mod, oracle):
     """the actor model of the reference (akka.conf:20-31): different workers run concurrently on a dispatcher's threads and
     a worker's thread may change between messages -- four handles driven from four threads at once (ctypes drops the GIL
