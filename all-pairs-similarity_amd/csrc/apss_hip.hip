@@ -652,43 +652,77 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   const int threads = 256;
   const int64_t blocks = ceil_div((h->idx_rows - r0) * kWave, threads);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  // bucketed build: tiles in GROUPS whose entries fit a bounded scratch (12 B per entry: a one-shot join of 2e9 entries would
+  // otherwise spend 1.2 s allocating 24 GB to save 0.5 s of atomics).  A single group (C5's shape at N = 2M: 4.8 GB) is bucketed
+  // once for both passes; several groups are bucketed again for the scatter pass (twice 43 ms at N = 10M, against 573 ms).
+  int64_t group_tiles = n_tiles;
+  BucketArgs bk{};
   if (bucket_build) {
-    const int64_t nb = n_tiles * n_ranges;
+    const int64_t per_tile = std::max<int64_t>(1, build_nnz / n_tiles);
+    group_tiles = std::max<int64_t>(1, std::min<int64_t>(n_tiles, (int64_t)6e8 / per_tile));
+    // entries of the largest group (row extents are on the device: one small read)
+    std::vector<int64_t> grp_e;
+    {
+      std::vector<int64_t> at;
+      for (int64_t g0 = 0; g0 < n_tiles; g0 += group_tiles) at.push_back(std::min<int64_t>(h->idx_rows, g0 * cb));
+      at.push_back(h->idx_rows);
+      grp_e.resize(at.size());
+      for (size_t i = 0; i < at.size(); ++i)
+        HIPCHK(h, hipMemcpyAsync(&grp_e[i], b.rowptr + at[i], sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    int64_t max_e = 1;
+    for (size_t i = 0; i + 1 < grp_e.size(); ++i) max_e = std::max(max_e, grp_e[i + 1] - grp_e[i]);
+    const int64_t nb = group_tiles * n_ranges;
     APSS_TRY(ensure(h, h->bk_cnt, (size_t)(2 * nb + 2)));
     APSS_TRY(ensure(h, h->bk_base, (size_t)nb + 2));
-    APSS_TRY(ensure(h, h->bk_idx, (size_t)build_nnz));
-    APSS_TRY(ensure(h, h->bk_erow, (size_t)build_nnz));
-    APSS_TRY(ensure(h, h->bk_val, (size_t)build_nnz));
-    HIPCHK(h, hipMemsetAsync(h->bk_cnt.p, 0, (size_t)(2 * nb + 2) * sizeof(unsigned long long), h->stream));
-    BucketArgs k{};
-    k.rowptr = b.rowptr;
-    k.idx = b.idx;
-    k.val = b.val;
-    k.erow = b.erow;
-    k.row1 = h->idx_rows;
-    k.cb = (int32_t)cb;
-    k.n_ranges = n_ranges;
-    k.range_terms = bucket_rt;
-    k.tile0 = 0;
-    k.bucket_cnt = h->bk_cnt.p;
-    k.bucket_cur = h->bk_cnt.p + nb + 1;
-    k.bucket_base = h->bk_base.p;
-    k.o_idx = h->bk_idx.p;
-    k.o_erow = h->bk_erow.p;
-    k.o_val = h->bk_val.p;
-    const dim3 bgrid((unsigned)(n_tiles * kBucketSlices));
-    hipLaunchKernelGGL(k_bucket_pass<false>, bgrid, dim3(1024), 0, h->stream, k);
-    APSS_TRY(scan_i64(h, reinterpret_cast<const int64_t *>(h->bk_cnt.p), h->bk_base.p, nb));
-    hipLaunchKernelGGL(k_bucket_pass<true>, bgrid, dim3(1024), 0, h->stream, k);
+    APSS_TRY(ensure(h, h->bk_idx, (size_t)max_e));
+    APSS_TRY(ensure(h, h->bk_erow, (size_t)max_e));
+    APSS_TRY(ensure(h, h->bk_val, (size_t)max_e));
+    bk.rowptr = b.rowptr;
+    bk.idx = b.idx;
+    bk.val = b.val;
+    bk.erow = b.erow;
+    bk.row1 = h->idx_rows;
+    bk.cb = (int32_t)cb;
+    bk.n_ranges = n_ranges;
+    bk.range_terms = bucket_rt;
+    bk.bucket_cnt = h->bk_cnt.p;
+    bk.bucket_cur = h->bk_cnt.p + nb + 1;
+    bk.bucket_base = h->bk_base.p;
+    bk.o_idx = h->bk_idx.p;
+    bk.o_erow = h->bk_erow.p;
+    bk.o_val = h->bk_val.p;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));  // (the build's clock starts behind the reservations)
+  }
+  // partition the entries of tiles [g0, g0 + gt) by term range into the scratch arrays (k_bucket_pass: count, scan, scatter)
+  auto bucket_group = [&](int64_t g0, int64_t gt) -> int32_t {
+    const int64_t nbg = gt * n_ranges;
+    HIPCHK(h, hipMemsetAsync(h->bk_cnt.p, 0, (size_t)(2 * (group_tiles * n_ranges) + 2) * sizeof(unsigned long long), h->stream));
+    bk.tile0 = g0;
+    const dim3 bgrid((unsigned)(gt * kBucketSlices));
+    hipLaunchKernelGGL(k_bucket_pass<false>, bgrid, dim3(1024), 0, h->stream, bk);
+    APSS_TRY(scan_i64(h, reinterpret_cast<const int64_t *>(h->bk_cnt.p), h->bk_base.p, nbg));
+    hipLaunchKernelGGL(k_bucket_pass<true>, bgrid, dim3(1024), 0, h->stream, bk);
     HIPCHK(h, hipGetLastError());
+    return APSS_OK;
+  };
+  if (bucket_build) {
     b.idx = h->bk_idx.p;
     b.erow = h->bk_erow.p;
     b.val = h->bk_val.p;
     b.ent_base = h->bk_base.p;
     b.range_terms = bucket_rt;
+    for (int64_t g0 = 0; g0 < n_tiles; g0 += group_tiles) {
+      const int64_t gt = std::min<int64_t>(group_tiles, n_tiles - g0);
+      APSS_TRY(bucket_group(g0, gt));
+      hipLaunchKernelGGL(k_tile_hist_lds, dim3((unsigned)(gt * n_ranges)), dim3(1024), 0, h->stream, b, g0, n_ranges);
+    }
+    HIPCHK(h, hipGetLastError());
   }
   const dim3 lds_grid((unsigned)((n_tiles - tile0) * n_ranges));
-  if (lds_build) hipLaunchKernelGGL(k_tile_hist_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
+  if (bucket_build) {}  // (counted above, group by group)
+  else if (lds_build) hipLaunchKernelGGL(k_tile_hist_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
   else hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
   APSS_TRY(launch_tile_scan(h, ix, tile0, n_tiles - tile0, lds_build ? 1u : 0u, tile0 == 0 ? ix.chunkw.p : nullptr, 1u));
   HIPCHK(h, hipGetLastError());
@@ -716,7 +750,13 @@ int32_t build_tiles(apss_handle *h, apss_handle::IndexSet &ix, int64_t row0) {
   b.tile_post_base = ix.base.p;
   b.post = ix.post.p;
   b.post_c = ix.post_c.p;
-  if (lds_build) hipLaunchKernelGGL(k_tile_scatter_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
+  if (bucket_build) {
+    for (int64_t g0 = 0; g0 < n_tiles; g0 += group_tiles) {
+      const int64_t gt = std::min<int64_t>(group_tiles, n_tiles - g0);
+      if (group_tiles < n_tiles) APSS_TRY(bucket_group(g0, gt));  // (a single group's buckets are still there)
+      hipLaunchKernelGGL(k_tile_scatter_lds, dim3((unsigned)(gt * n_ranges)), dim3(1024), 0, h->stream, b, g0, n_ranges);
+    }
+  } else if (lds_build) hipLaunchKernelGGL(k_tile_scatter_lds, lds_grid, dim3(1024), 0, h->stream, b, tile0, n_ranges);
   else hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)blocks), dim3(threads), 0, h->stream, b);
   if (ix.coarse && ix.cb <= 32768 && h->dbgcfg.bank_order)
     hipLaunchKernelGGL(k_seg_bank_order, dim3((unsigned)ceil_div((n_tiles - tile0) * stride * kWave, 256)), dim3(256), 0, h->stream,
