@@ -426,13 +426,16 @@ def multi_gpu(a, cfg, rp, idx, val, dev, comm_dev, rank, world, local_rank, sync
     if not a.no_comparison_row and T != 1:
         comp = timed(1, "comparison layout: candidate ranges")
         extra["candidate_range_layout"] = comp
-        assert comp["result_pairs_per_step"] == head["result_pairs_per_step"], "the two layouts disagree on the result set size"
+        # (same set up to the pairs within an ulp of theta: a row-range cell reports a cross pair in both directions with ONE fp32
+        # score, a term shard sums each direction in its own order -- |score - theta| <= 1e-5 may differ)
+        same = lambda x, y: abs(x - y) <= max(4, int(2e-5 * max(x, y)))  # noqa: E731
+        assert same(comp["result_pairs_per_step"], head["result_pairs_per_step"]), "the two layouts disagree on the result set size"
         if world >= 4 and world % 2 == 0 and T == world:
             # the grid between the two: 2 term ranges x N/2 candidate ranges -- still a term-sharded index with the RCCL exchange of
             # partial scores inside every pair, but rounds four times as fat as at T = N (projected fastest)
             mid = timed(2, "comparison layout: 2 term ranges x %d candidate ranges" % (world // 2))
             extra["grid_2_term_ranges_layout"] = mid
-            assert mid["result_pairs_per_step"] == head["result_pairs_per_step"], "the grids disagree on the result set size"
+            assert same(mid["result_pairs_per_step"], head["result_pairs_per_step"]), "the grids disagree on the result set size"
     out = {
         "value": head["value"], "ms_per_step": head["ms_per_step"],
         "posting_visits_per_step": head["posting_visits_per_step"], "candidate_pairs_per_step": cands,
