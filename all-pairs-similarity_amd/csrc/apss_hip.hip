@@ -1234,14 +1234,18 @@ int32_t build_index(apss_handle *h, int64_t row0) {
   return APSS_OK;
 }
 
-template <int MODE, bool FX>
+template <int MODE, bool FX, int BLOCK = kProbeBlock>
 int32_t launch_probe(apss_handle *h, const ProbeArgs &a, size_t lds) {
-  auto kern = k_probe<MODE, kProbeBlock, FX>;
+  auto kern = k_probe<MODE, BLOCK, FX>;
   HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(kProbeBlock), lds, h->stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.n_tiles * a.n_chunks)), dim3(BLOCK), lds, h->stream, a);
   HIPCHK(h, hipGetLastError());
   return APSS_OK;
 }
+// theta <= 0 (every touched candidate is an answer): the round is a chain of barriers and latencies (SQ counters, round 4:
+// 73 % of the wave-cycles waiting, LDS issue 0.39, VALU 0.34), and the 1024-thread workgroup over a 16384-row tile holds 93 KB
+// of LDS: ONE workgroup per CU.  512 threads over tiles of <= 8192 rows hold 58 KB: two per CU
+inline int gen_block(int mode, int cb) { return mode == 2 && cb <= 8192 ? 512 : kProbeBlock; }
 
 // ---- the filter kernel's instantiations: (threads, register-window steps, shard rule, postings per chunk, virtual
 // rows, signed weights).  One table, one lookup: a combination that is not listed is an error, never another kernel.
@@ -1965,7 +1969,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // (the filter kernels keep their LDS in static arrays: no dynamic allocation)
   const size_t lds = coarse_path ? 0
                      : wave_path ? probe_wave_lds_bytes(h->ex.cb, wave_block, wave_u, wave_longcap, wave_survcap)
-                                 : probe_lds_bytes(h->ex.cb, kProbeBlock, mode);
+                                 : probe_lds_bytes(h->ex.cb, gen_block(mode, h->ex.cb), mode);
   auto launch_wave = [&](bool diag) -> int32_t {
     const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
 #define APSS_LAUNCH_WAVE1(B, UU, LC, SC, SH, DG)                                                                         \
@@ -2047,7 +2051,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       else if (wave_path)
         snprintf(nm, cap, "k_probe_wave<%d, %d, %d, %d, %s, %s>", wave_block, wave_u, wave_longcap, wave_survcap, tf(h->sharded), tf(dbg.diag));
       else
-        snprintf(nm, cap, "k_probe<%d, %d, %s>", mode, kProbeBlock, tf(gen_fx));
+        snprintf(nm, cap, "k_probe<%d, %d, %s>", mode, gen_block(mode, h->ex.cb), tf(gen_fx));
     }
     for (int64_t t0 = 0; t0 < total_tiles; t0 += tiles_per_launch, ++n_launches) {
       a.tile0 = (int32_t)t0;
@@ -2075,10 +2079,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       } else if (gen_fx) {
         if (mode == 0) APSS_TRY((launch_probe<0, true>(h, a, lds)));
         else if (mode == 1) APSS_TRY((launch_probe<1, true>(h, a, lds)));
+        else if (gen_block(2, h->ex.cb) == 512) APSS_TRY((launch_probe<2, true, 512>(h, a, lds)));
         else APSS_TRY((launch_probe<2, true>(h, a, lds)));
       } else {
         if (mode == 0) APSS_TRY((launch_probe<0, false>(h, a, lds)));
         else if (mode == 1) APSS_TRY((launch_probe<1, false>(h, a, lds)));
+        else if (gen_block(2, h->ex.cb) == 512) APSS_TRY((launch_probe<2, false, 512>(h, a, lds)));
         else APSS_TRY((launch_probe<2, false>(h, a, lds)));
       }
     }  // tile groups
@@ -2403,7 +2409,7 @@ int32_t apss_create(const apss_config *cfg, apss_handle **out) {
   // their survivors are the shard's candidates, scored exactly in phase 2.  APSS_SHARD_EXACT=1: single-pass kernel.
   h->use_coarse = !(cfg->flags & (APSS_FLAG_EXACT_ACCUM | APSS_FLAG_FORCE_GENERAL | APSS_FLAG_FORCE_SCAN)) &&
                   (!h->sharded || !h->dbgcfg.shard_exact);
-  h->cb = cfg->tile_rows ? cfg->tile_rows : 16384;
+  h->cb = cfg->tile_rows ? cfg->tile_rows : (cfg->theta > 0.0 ? 16384 : 8192);  // (theta <= 0: gen_block, two workgroups per CU)
   h->ex.cb = h->cb;
   h->ex.align = kSegAlign;
   h->cx.cb = std::min(2 * h->cb, 32768);
