@@ -46,7 +46,8 @@ class Stats(C.Structure):
                 ("head_ms", C.c_double), ("head_flops", C.c_double), ("thin_launches", C.c_int64),
                 ("downgrades", C.c_uint32), ("head_columns", C.c_uint32), ("probe_kernel", C.c_char * 96),
                 ("device_posting_visits", C.c_int64), ("symmetric_declined", C.c_uint32), ("query_chunk", C.c_int32),
-                ("filter_tile_rows", C.c_int32), ("head_int8", C.c_int32)]
+                ("filter_tile_rows", C.c_int32), ("head_int8", C.c_int32),
+                ("queries_per_round", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class GroupStats(C.Structure):

@@ -40,8 +40,8 @@
 
 namespace apss {
 
-template <int BLOCK, int U, int LONGCAP, bool SHARD, bool SIGNED, bool ACC8>
-__global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_even(const ProbeArgs a) {
+template <int BLOCK, int U, int LONGCAP, bool SHARD, bool SIGNED, bool ACC8, bool MERGE>
+__device__ __forceinline__ void probe_even_body(const ProbeArgs &a) {
   // (Tried for C3's full rounds: workgroups of TEN waves -- the eight adding waves of the 512-thread kernel plus two staging
   // waves, 87 VGPRs at five steps.  143 vs 111 ms: ten waves spread 3/3/2/2 over the SIMDs and the second workgroup of a CU
   // needs a SIMD to hold six of them, i.e. <= 80 VGPRs; it did not become resident.)
@@ -87,16 +87,34 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const uint32_t sub = (uint32_t)ln & (uint32_t)(G - 1);
   const int tile = a.tile0 + blockIdx.x / a.n_chunks;
   const int chunk = blockIdx.x % a.n_chunks;
-  const int v0 = chunk * a.q_chunk;
-  const int v1 = min(a.nq, v0 + a.q_chunk);
-  const int nv = a.nq;
-  const int qtile = v0 / cb;  // (symmetric joins: the chunk lies inside one tile)
+  // MERGED rounds (ProbeArgs::merge_log2 = m > 0): round v stages the terms of the M = 2^m query rows M v .. M v + M - 1 as
+  // ONE row -- they are neighbours in the CSR arrays, so the merged row is the extent rowptr[M v] .. rowptr[M v + M) -- and a
+  // candidate's accumulator holds the SUM of its M filter sums: an upper bound of each of them (non-negative weights), so a
+  // candidate that stays below the threshold fails for every query of the round, and a crossing is reported for the round
+  // (k_expand_merged turns it into M survivors; the exact pass / the shard's phase 2 prunes as ever).  a.nq, a.q_chunk and v
+  // count ROUNDS; a.nq_rows the rows; a.q_val holds the rows' weights already divided by their shard factors.
+  // NOT where a query meets ITSELF: a stored row's product with its own slot crosses the threshold by itself, and the crossing
+  // would stand for its M - 1 neighbours too (one false survivor per query and shard).  A workgroup whose candidate tile holds
+  // rows of its own chunk (the diagonal of a whole-store join, the last tiles of an appended batch) runs its rows ONE per round
+  // (`mlog` = 0 for this workgroup, on the launch's smaller scale) and marks what it reports with kUnmergedBit.
+  // (MERGE: instantiations of their own -- the handful of scalars this costs took the unmerged shard kernel to its SGPR limit: 13.0 -> 13.9 ms at T = 8)
+  static_assert(!MERGE || SHARD, "merged rounds: term shards only");
+  const int mlaunch = MERGE ? a.merge_log2 : 0;
+  const int c0 = chunk * a.q_chunk;
+  const int row_lo = c0 << mlaunch, row_hi = MERGE ? min(a.nq_rows, (c0 + a.q_chunk) << mlaunch) : 0;  // this workgroup's query rows
+  const bool own_tile = mlaunch != 0 && a.q_slot_base >= 0 && (a.q_slot_base + row_lo) / cb <= tile && tile <= (a.q_slot_base + row_hi - 1) / cb;
+  const int mlog = own_tile ? 0 : mlaunch;
+  const int v0 = row_lo >> mlog;
+  const int v1 = own_tile ? row_hi : min(a.nq, c0 + a.q_chunk);
+  const int nv = own_tile ? a.nq_rows : a.nq;
+  const int qtile = row_lo / cb;  // (symmetric joins: the chunk lies inside one tile)
   if (a.tri && tile > qtile) return;  // the mirrored half (ProbeArgs::tri): before any barrier, the whole workgroup
   const int64_t tile_row0 = (int64_t)tile * cb;
+  const int unmerged_mark = own_tile ? kUnmergedBit : 0;
   const uint32_t lo = (uint32_t)(ln % LPC);
   const float cxs = a.cx_scale;
 
-  const int64_t qbase = a.q_rowptr[v0], qend = a.q_rowptr[v1];
+  const int64_t qbase = a.q_rowptr[MERGE ? min(v0 << mlog, a.nq_rows) : v0], qend = a.q_rowptr[MERGE ? min(v1 << mlog, a.nq_rows) : v1];
   const int64_t pbase = a.tile_post_base[tile], pend = a.tile_post_base[tile + 1];
   const __amdgpu_buffer_rsrc_t rs_qi =
       __builtin_amdgcn_make_buffer_rsrc((void *)(a.q_idx + qbase), 0, (int)((qend - qbase) * 4), 0x00020000);
@@ -141,9 +159,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
   const int qbase_lo = (int)(uint32_t)qbase;
   auto load_R = [&](int v) {  // raw: the low halves of rowptr[v], rowptr[v + 1]
     RowExt r;
-    const int vv = min(v, nv - 1);
-    r.qb = rowptr_lo[2 * vv];
-    r.nnz = rowptr_lo[2 * vv + 2];
+    const int row_a = min(v, nv - 1) << mlog, row_b = MERGE ? min(row_a + (1 << mlog), a.nq_rows) : row_a + 1;
+    r.qb = rowptr_lo[2 * row_a];
+    r.nnz = rowptr_lo[2 * row_b];
     return r;
   };
   auto load_I = [&](const RowExt &r, const int fi, const int v) {
@@ -154,7 +172,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     const uint32_t off = t.valid ? (uint32_t)(r.qb - qbase_lo + kterm) * 4u : kOob;  // (< 2^31: a workgroup's slice of the batch)
     t.term = __builtin_amdgcn_raw_buffer_load_b32(rs_qi, off, 0, 0);
     t.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qv, off, 0, 0));
-    t.qs = SHARD ? a.q_scale[min(v, nv - 1)] : 1.0f;  // shard rule: |q_g| / |q|, the query's half of the normalisation
+    t.qs = SHARD && !MERGE ? a.q_scale[min(v, nv - 1)] : 1.0f;  // shard rule: |q_g| / |q|, the query's half of the normalisation
     return t;
   };
   auto load_P = [&](const TermW &t) {
@@ -324,20 +342,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
       // a crossing, reported by the wave that sees it (uniform control flow: one global atomic per wave and call)
       auto report = [&](const bool cross, const uint32_t slot, const uint32_t sum) {
         bool ok = cross;
-        if (ok) ok = a.ext_id[tile_row0 + slot] != a.q_ext[q];
+        if (ok && mlog == 0) ok = a.ext_id[tile_row0 + slot] != a.q_ext[q];  // (merged rounds: k_expand_merged excludes)
         const uint64_t o = wave_append(ok, &a.counters[kCtrResults]);
         if (ok && o < a.res_cap) {
-          a.res_q[o] = q;
+          a.res_q[o] = q | unmerged_mark;
           a.res_c[o] = (int32_t)(tile_row0 + slot);
           a.res_s[o] = (float)sum / cxs;  // coarse score at the crossing, replaced by k_rescore
         }
       };
       // the same from divergent control flow (sweeps): one atomic per lane
       auto report_lane = [&](const uint32_t slot, const uint32_t sum) {
-        if (a.ext_id[tile_row0 + slot] != a.q_ext[q]) {
+        if (mlog != 0 || a.ext_id[tile_row0 + slot] != a.q_ext[q]) {
           const uint64_t o = atomicAdd(&a.counters[kCtrResults], 1ull);
           if (o < a.res_cap) {
-            a.res_q[o] = q;
+            a.res_q[o] = q | unmerged_mark;
             a.res_c[o] = (int32_t)(tile_row0 + slot);
             a.res_s[o] = (float)sum / cxs;
           }
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
           RowExt cur = load_R(v);
           cur.nnz -= cur.qb;
           cur.qb -= qbase_lo;
-          const float qsv = SHARD ? uniform_load(a.q_scale + v) : 1.0f;
+          const float qsv = SHARD && !MERGE ? uniform_load(a.q_scale + v) : 1.0f;
           const float iq = qsv > 0.f ? 1.0f / qsv : 0.f;
           for (int k = rank; k < cur.nnz; k += A) {
             const uint32_t off = (uint32_t)(cur.qb + k) * 4u;
@@ -523,6 +541,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256
     atomicAdd(&a.counters[kCtrCands], stat[1] * twice);
     atomicAdd(&a.counters[kCtrDevVisits], stat[0]);
   }
+}
+
+template <int BLOCK, int U, int LONGCAP, bool SHARD, bool SIGNED, bool ACC8>
+__global__ __launch_bounds__(BLOCK, BLOCK <= 512 ? 2 * BLOCK / 256 : BLOCK / 256) void k_probe_even(const ProbeArgs a) {
+  probe_even_body<BLOCK, U, LONGCAP, SHARD, SIGNED, ACC8, false>(a);
+}
+
+// the same rounds with M = 2^merge_log2 neighbouring query rows each (a term shard's thin rounds; see MERGED rounds above)
+template <int U, bool ACC8>
+__global__ __launch_bounds__(512, 4) void k_probe_even_merged(const ProbeArgs a) {
+  probe_even_body<512, U, 128, true, false, ACC8, true>(a);
 }
 
 }  // namespace apss

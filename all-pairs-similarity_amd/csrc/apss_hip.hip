@@ -64,6 +64,9 @@ struct DebugCfg {
   int bucket_range = 0;        // bucket_range=N terms per range of the bucketed LDS build (a power of two <= 16384; default 2048)
   int res_cap = 0;             // res_cap=N      initial capacity of the candidate list (tests of the overflow -> regrow -> re-run path)
   bool head_bf16 = false;      // head_bf16      the dense-head block keeps bf16 rows (v_mfma_f32_32x32x16_bf16), never the INT8 rendering
+  int merge = -1;              // merge=L        a term shard's thin rounds: at most 2^L query rows share a round (0: never; default 1: two rows)
+  int merge_u = 0;             // merge_u=U      ... as long as the merged round fits a window of U steps (default 7)
+  int merge_single = 0;        // merge_single=U ... and a single row's round takes a window of at most U steps (default 4)
 };
 
 DebugCfg parse_debug_env() {
@@ -109,6 +112,9 @@ DebugCfg parse_debug_env() {
     else if (key == "res_cap") d.res_cap = val;
     else if (key == "no_bucket") d.no_bucket = val != 0;
     else if (key == "bucket_range") d.bucket_range = val;
+    else if (key == "merge") d.merge = (int)val;
+    else if (key == "merge_u") d.merge_u = (int)val;
+    else if (key == "merge_single") d.merge_single = (int)val;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
   return d;
@@ -191,6 +197,8 @@ struct apss_handle {
   // results of the last query-type call
   DevBuf<int32_t> res_q, res_c, fin_q, fin_c;
   DevBuf<float> res_s, fin_s;
+  DevBuf<int32_t> res2_q, res2_c;    // merged rounds (k_expand_merged): the second candidate list, swapped with res_* after the expansion
+  DevBuf<float> res2_s, q_prenorm;   // ... and the staged query weights divided by their rows' shard factors
   const int32_t *out_q = nullptr, *out_c = nullptr;  // where the last call's results live (res_* or fin_*)
   const float *out_s = nullptr;
   int64_t n_res = -1;
@@ -216,6 +224,7 @@ struct apss_handle {
   int32_t head_fold_w = 128;
   int32_t head_exact = 128;
   int32_t head_fold_user = 0;         // folded columns named by the caller for the terms it sets (apss_set_head_fold; 0: 128)
+  bool merge_off = false;             // term shard: merged rounds (apss_even.hpp) reported too many candidates on this data: not again (until apss_clear)
   bool head_longseg = false;          // term shard with a block: its tail still has segments too long for the thin-round kernel (a
                                       // hint kept across apss_clear: the next first build goes straight to the layout that serves them)
   int32_t head_part = 0, head_parts = 1;  // this handle multiplies the candidate tiles t % head_parts == head_part of the block
@@ -1291,6 +1300,7 @@ struct CxVariant {
   bool longpf;  // prefetched long-segment sweeps: the sparse half of a handle with a dense-head block
   bool acc8;    // 8-bit accumulators over 65536-row tiles: thin rounds of a term shard
   bool even;    // k_probe_even: a round is staged by ceil(longest query / 64) waves and its chunks dealt out evenly
+  bool merge;   // k_probe_even<.., MERGE>: neighbouring query rows share a round (term shards)
 };
 
 // k_probe_even's instantiations: (threads, window steps, shard rule, signed weights, 8-bit accumulators)
@@ -1324,8 +1334,19 @@ struct CxVariant {
   X(1024, 6, false, false, true)       \
   X(1024, 5, false, false, true)       \
   X(1024, 3, false, false, true)
+// ... and with MERGE (shard rule, non-negative weights): (window steps, 8-bit accumulators)
+#define APSS_EVEN_MERGE_VARIANTS(X) \
+  X(7, false) X(6, false) X(5, false) X(4, false) X(3, false) X(2, false) \
+  X(7, true) X(6, true) X(5, true) X(4, true) X(3, true) X(2, true)
 
 bool cx_variant_exists(const CxVariant &v) {
+  if (v.even && v.merge) {
+#define X(U, A8) \
+    if (v.block == 512 && v.u == U && v.shard && !v.sgn && v.acc8 == A8) return v.chunk == 16 && !v.vrows && !v.longpf;
+    APSS_EVEN_MERGE_VARIANTS(X)
+#undef X
+    return false;
+  }
   if (v.even) {
 #define X(B, U, SH, SG, A8) \
     if (v.block == B && v.u == U && v.shard == SH && v.sgn == SG && v.acc8 == A8) return v.chunk == 16 && !v.vrows && !v.longpf;
@@ -1343,7 +1364,18 @@ bool cx_variant_exists(const CxVariant &v) {
 }
 
 int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
-  const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
+ const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
+  if (v.even && v.merge) {
+#define X(U, A8)                                                                                                           \
+    if (v.block == 512 && v.u == U && v.acc8 == A8) {                                                                      \
+      hipLaunchKernelGGL((k_probe_even_merged<U, A8>), grid, dim3(512), (size_t)h->dbgcfg.pad_lds, h->stream, a);           \
+      HIPCHK(h, hipGetLastError());                                                                                        \
+      return APSS_OK;                                                                                                      \
+    }
+    APSS_EVEN_MERGE_VARIANTS(X)
+#undef X
+    return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
+  }
   if (v.even) {
 #define X(B, U, SH, SG, A8)                                                                                                \
     if (v.block == B && v.u == U && v.shard == SH && v.sgn == SG && v.acc8 == A8) {                                        \
@@ -1495,6 +1527,7 @@ struct FilterFacts {
   bool hybrid;       // the handle has a dense-head block
   int64_t s_max_nnz, s_nnz_end;  // longest staged query row, elements staged
   int64_t nq, idx_nnz;           // query rows, postings in the inverted index
+  int max_merge_log2;            // k_probe_even: up to 2^this query rows may share a round (0: none)
 };
 
 // ---- which instantiation of the filter kernel: the register window (U steps of 8 chunks per wave) is sized for the
@@ -1541,10 +1574,6 @@ int32_t plan_filter(apss_handle *h, const FilterFacts &f, CxVariant &cxv, ProbeA
   // k_probe_even (apss_even.hpp): F waves stage the round, the others add an even share of its chunks -- a wave's window
   // then holds a 1/A share of the ROUND's chunks, not the chunks of the wave's own terms.
   // Staging lanes per term: as many as keep the staging waves at <= a quarter of the workgroup.
-  int flat_group_log2 = 2;
-  while (flat_group_log2 > 0 && ceil_div(f.s_max_nnz, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
-  if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
-  const int64_t flat_waves = std::max<int64_t>(1, ceil_div(f.s_max_nnz, kWave >> flat_group_log2));
   // Where it is taken (measured on C3 and its shards, ms of the filter kernel, k_probe_even vs k_probe_coarse): term shards
   // T = 8: 23.4 vs 40.5, T = 4: 35.6 vs 62.4, T = 2 (one staging lane per term, 7-step windows): 58.7 vs 77.9; the sparse
   // regime's 1024-thread kernel (C5's shape at a fifth of N): 218.2 vs 291.5; the plain handle of C3 itself (100-term rows,
@@ -1555,23 +1584,37 @@ int32_t plan_filter(apss_handle *h, const FilterFacts &f, CxVariant &cxv, ProbeA
   // path, meant for one round in a few.  C3 with Zipf(0.5) terms, ~400 long terms per tile and half a dozen in every round,
   // measured 1395 ms there against 518 ms on k_probe_coarse)
   const bool few_longs = (double)h->cx.long_segs <= 16.0 * (double)std::max<int64_t>(1, h->cx.n_tiles) || f.shard_rule || cxv.block == 1024;
-  if (!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4 && few_longs) {
+  // MERGED rounds (apss_even.hpp): M = 2^m neighbouring query rows staged as one row, when a single query's round is thin (a
+  // window of <= 4 steps) and the merged round still fits a window; the caller says how many the accumulators have room for
+  a.merge_log2 = 0;
+  int ue_single = 0;
+  for (int m = 0; m <= f.max_merge_log2; ++m) {
+    const int64_t M = 1LL << m;
+    const int64_t row_max = std::min<int64_t>(f.s_max_nnz * M, f.s_nnz_end);  // longest staged row: at most M of the longest
+    int flat_group_log2 = 2;
+    while (flat_group_log2 > 0 && ceil_div(row_max, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
+    if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
+    const int64_t flat_waves = std::max<int64_t>(1, ceil_div(row_max, kWave >> flat_group_log2));
+    if (!(!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4 && few_longs)) break;
     CxVariant ev = cxv;
     ev.even = true;
+    ev.merge = m > 0;
     const double add_waves = nw - (double)flat_waves;               // a wave that stages a round adds nothing in it
     // postings per (tile, term) over the terms this handle indexes (a term shard: its range, not the whole dimension)
     const double seg_here = seg * (double)h->cfg.dim / (double)std::max<int64_t>(1, (int64_t)h->cfg.term_hi - h->cfg.term_lo);
     const double cpt = std::max(1.0, seg_here / 16.0 + 0.5);      // chunks per term
+    const double mq_terms = q_terms * (double)M;                    // terms of a round
     // (mean + 2 sigma of a binomial share of the terms: the rounds beyond read their last chunks from the strip and end
     // with a whole-tile clear, ~2 % of them; at 3 sigma the T = 8 shard took a 3-step window: 24.8 vs 23.2 ms)
-    double round_chunks = q_terms * cpt + 2.0 * std::sqrt(q_terms * cpt * cpt + q_terms * 0.3);
+    double round_chunks = mq_terms * cpt + 2.0 * std::sqrt(mq_terms * cpt * cpt + mq_terms * 0.3);
     // ... that is the uniform-terms estimate; the index build MEASURED what an average stored row deals out per tile
     // (sum over terms of P(term in the row) x chunks of its segment): under a skewed distribution the terms a query holds
     // are the ones with the long segments, and the estimate above falls short by a factor (power-law C5's tail: 85
     // estimated, 200 dealt out: most rounds overflowed their window, a whole-tile clear each)
     if (h->cx.round_chunks > 0.0) {
-      const double per_term = std::max(1.0, h->cx.round_chunks / std::max(1.0, q_terms));
-      round_chunks = std::max(round_chunks, h->cx.round_chunks + 2.0 * std::sqrt(h->cx.round_chunks * per_term));
+      const double rc = h->cx.round_chunks * (double)M;
+      const double per_term = std::max(1.0, rc / std::max(1.0, mq_terms));
+      round_chunks = std::max(round_chunks, rc + 2.0 * std::sqrt(rc * per_term));
     }
     // (a plain handle's rows are whole rows: no binomial share of the terms; the longest row bounds the round)
     if (!f.shard_rule) round_chunks = std::min(round_chunks, 1.05 * (double)f.s_max_nnz * cpt);
@@ -1581,13 +1624,19 @@ int32_t plan_filter(apss_handle *h, const FilterFacts &f, CxVariant &cxv, ProbeA
     ue = cxv.block == 1024 ? (ue <= 3 ? 3 : std::max(5, ue)) : std::max(2, ue);
     ev.u = ue;
     if (dbg.diag)
-      fprintf(stderr, "[apss diag] even? block %d u %d | F %lld G %d A %.0f chunks %.1f ue %d fits %d exists %d q_max %lld q_terms %.1f seg %.1f\n", cxv.block, cxv.u,
-              (long long)flat_waves, 1 << flat_group_log2, add_waves, round_chunks, ue, (int)fits, (int)cx_variant_exists(ev), (long long)f.s_max_nnz, q_terms, seg);
-    if (fits && cx_variant_exists(ev)) {
-      cxv = ev;
-      a.flat_waves = (int32_t)flat_waves;
-      a.flat_group_log2 = flat_group_log2;
-    }
+      fprintf(stderr, "[apss diag] even? merge %lld block %d u %d | F %lld G %d A %.0f chunks %.1f ue %d fits %d exists %d q_max %lld q_terms %.1f seg %.1f\n",
+              (long long)M, cxv.block, cxv.u, (long long)flat_waves, 1 << flat_group_log2, add_waves, round_chunks, ue, (int)fits,
+              (int)cx_variant_exists(ev), (long long)f.s_max_nnz, q_terms, seg);
+    if (m == 0) ue_single = ue;
+    if (!(fits && cx_variant_exists(ev))) break;
+    // (measured on C3's shards, filter kernel: T = 8, window 2 -> 4 steps: 13.1 -> 11.1 ms; T = 4, 4 -> 7 steps: 19.9 -> 17.3 ms; T = 2
+    // needs its 7 steps for one row.  FOUR rows per round at T = 8, 7 steps and 2^5 units per 1.0: 10.6 ms but 6.5 x the
+    // candidates for the exchange -- not by default, APSS_DEBUG=merge=2)
+    if (m > 0 && !(ue_single <= (dbg.merge_single > 0 ? dbg.merge_single : 4) && ue <= (dbg.merge_u > 0 ? dbg.merge_u : 7))) break;
+    cxv = ev;
+    a.flat_waves = (int32_t)flat_waves;
+    a.flat_group_log2 = flat_group_log2;
+    a.merge_log2 = m;
   }
   if (!cx_variant_exists(cxv)) return fail(h, APSS_E_UNSUPPORTED, "no filter kernel for this combination of options");
   return APSS_OK;
@@ -1883,6 +1932,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.q_ext = q_ext;
   a.q_scale = shard_rule ? q_sub : nullptr;
   a.nq = (int32_t)nq;
+  a.nq_rows = (int32_t)nq;
   a.q_nnz_end = s_nnz_end;
   // ~2 workgroups per CU per tile in flight at once, tiles swept one after another (tile-major grid) so the
   // chip works on one tile's postings at a time and they stay in L2 / Infinity Cache
@@ -1932,9 +1982,40 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   a.theta_fx = (uint32_t)std::min(4294967295.0, std::max(1.0, std::ceil(theta * scale_used)));
   a.theta_fxi = (int32_t)std::max(-2147483647.0, std::min(2147483647.0, std::ceil(theta * scale_used)));
 
+  // MERGED rounds (a term shard's thin rounds, apss_even.hpp): M neighbouring query rows share a round, their M filter sums one
+  // accumulator -- which then has to hold M sums: the scale for M rows is the scale of one row with M times the norm bound and
+  // M times the shared terms.  How many rows the accumulators have room for (plan_filter decides how many a window has):
+  auto merged_scale = [&](int m) -> double {
+    const double Mx = (double)(1 << m);
+    if (a8_scale > 0) return acc8_scale(bound * Mx, cx_shared * Mx, theta);
+    for (int k = 15; k >= 4; --k) {
+      const double S = std::ldexp(1.0, k);
+      if (bound * Mx * 1.0005 * S < 65535.0 - cx_shared * Mx)
+        return S >= 16384.0 || std::floor(theta * S * (1.0 - 1.0 / 2048 - 1e-6)) >= 4.0 * cx_shared * Mx ? S : 0.0;
+    }
+    return 0.0;
+  };
+  // ... and how many the filter stays SELECTIVE with: a chance pair collects about 1 / t of the threshold's scale per shared term
+  // (t = terms of a row inside this shard), and a round of M rows hits a given candidate M t^2 / R times on average (R = terms
+  // of the range).  Rows of a dozen terms over thousands of terms (C3's shards: t = 12.5, R = 12500): a chance candidate is
+  // hit once, by one row.  Rows of three or four terms over a few hundred: three chance hits from different rows of a round
+  // cross the threshold (measured: 8 x more candidates than unmerged) -- not there.  A fuse behind the estimate: a merged
+  // launch that reports more than two rounds per query row turns merging off for the handle (merge_off).
+  const double t_shard = (double)s_nnz_end / (double)std::max<int64_t>(nq, 1);
+  const double r_shard = (double)std::max<int64_t>(1, (int64_t)h->cfg.term_hi - h->cfg.term_lo);
+  int max_merge_log2 = 0;
+  if (coarse_path && h->sharded && !hybrid_wanted && mode == 0 && !cx_signed && dbg.merge != 0 && !h->merge_off && t_shard >= 8.0)
+    while (max_merge_log2 < (dbg.merge > 0 ? std::min(dbg.merge, 2) : 1) && (nq >> (max_merge_log2 + 1)) >= 1 &&
+           (double)(2 << max_merge_log2) * t_shard * t_shard <= 0.25 * r_shard && merged_scale(max_merge_log2 + 1) > 0)
+      ++max_merge_log2;
   CxVariant cxv{};
   if (coarse_path)
-    APSS_TRY(plan_filter(h, FilterFacts{a8_scale > 0, shard_rule, cx_signed, hybrid_wanted, s_max_nnz, s_nnz_end, nq, idx_nnz}, cxv, a));
+    APSS_TRY(plan_filter(h, FilterFacts{a8_scale > 0, shard_rule, cx_signed, hybrid_wanted, s_max_nnz, s_nnz_end, nq, idx_nnz, max_merge_log2}, cxv, a));
+  if (a.merge_log2 > 0) {
+    const double S = merged_scale(a.merge_log2);
+    a.cx_scale = (float)S;
+    a.cx_theta = (float)std::floor(theta * S * (1.0 - 1.0 / 2048 - 1e-6));
+  }
   // ---- SYMMETRIC whole-store join: the batch IS the indexed store (query row v = stored row v: apss_self_join, or
   // insert-and-query into an empty handle), so the pair (q, c) and the pair (c, q) share their terms and their score.  The
   // filter runs a (query tile S, candidate tile T) workgroup only for T <= S and k_mirror_survivors adds the other direction
@@ -1965,6 +2046,19 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.symmetric_declined = sym_declined;
   h->st.query_chunk = a.q_chunk;
   h->st.filter_tile_rows = ix.cb;
+  h->st.queries_per_round = 1 << a.merge_log2;
+  if (a.merge_log2 > 0) {
+    // from here on the launch counts ROUNDS: a chunk is a whole number of them (a symmetric join's power of two stays one)
+    const int64_t M = 1LL << a.merge_log2;
+    const int64_t qc = ceil_div(a.q_chunk, M) * M;
+    a.q_chunk = (int32_t)(qc / M);
+    a.n_chunks = (int32_t)ceil_div(nq, qc);
+    a.nq = (int32_t)ceil_div(nq, M);
+    APSS_TRY(ensure(h, h->q_prenorm, (size_t)s_nnz_end));
+    hipLaunchKernelGGL(k_prenorm_rows, dim3((unsigned)ceil_div(nq * kGroup, 256)), dim3(256), 0, h->stream, s_rowptr, s_val, q_sub, nq, h->q_prenorm.p);
+    HIPCHK(h, hipGetLastError());
+    a.q_val = h->q_prenorm.p;
+  }
   const int vrow_part = 512;
   // (the filter kernels keep their LDS in static arrays: no dynamic allocation)
   const size_t lds = coarse_path ? 0
@@ -2031,6 +2125,11 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       APSS_TRY(ensure(h, h->fin_c, fin_cap));
       APSS_TRY(ensure(h, h->fin_s, fin_cap));
     }
+    if (a.merge_log2 > 0) {  // (k_expand_merged writes the pairs out of place)
+      APSS_TRY(ensure(h, h->res2_q, h->res_q.cap, 0, true));
+      APSS_TRY(ensure(h, h->res2_c, h->res_q.cap, 0, true));
+      APSS_TRY(ensure(h, h->res2_s, h->res_q.cap, 0, true));
+    }
     a.dbg = nullptr;
     a.res_q = h->res_q.p;
     a.res_c = h->res_c.p;
@@ -2044,7 +2143,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       char *nm = h->st.probe_kernel;
       const size_t cap = sizeof(h->st.probe_kernel);
       if (coarse_path && cxv.even)
-        snprintf(nm, cap, "k_probe_even<%d, %d, %d, %s, %s, %s>", cxv.block, cxv.u, cxv.block <= 512 ? 128 : 256, tf(cxv.shard), tf(cxv.sgn), tf(cxv.acc8));
+        if (cxv.merge) snprintf(nm, cap, "k_probe_even_merged<%d, %s>", cxv.u, tf(cxv.acc8));
+        else snprintf(nm, cap, "k_probe_even<%d, %d, %d, %s, %s, %s>", cxv.block, cxv.u, cxv.block <= 512 ? 128 : 256, tf(cxv.shard), tf(cxv.sgn), tf(cxv.acc8));
       else if (coarse_path)
         snprintf(nm, cap, "k_probe_coarse<%d, %d, %d, %d, %s, %d, %s, %s, %s, %s>", cxv.block, cxv.u, cxv.block <= 512 ? 128 : 256,
                  cxv.block <= 512 ? 512 : 1024, tf(cxv.shard), cxv.chunk, tf(cxv.vrows), tf(cxv.sgn), tf(cxv.longpf), tf(cxv.acc8));
@@ -2088,6 +2188,21 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
         else APSS_TRY((launch_probe<2, false>(h, a, lds)));
       }
     }  // tile groups
+    if (a.merge_log2 > 0) {  // (round, candidate) -> the round's (query row, candidate) pairs
+      HIPCHK(h, hipMemcpyAsync(h->counters.p + kCtrPre, h->counters.p + kCtrResults, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(h, hipMemsetAsync(h->counters.p + kCtrResults, 0, sizeof(unsigned long long), h->stream));
+      hipLaunchKernelGGL(k_expand_merged, dim3(1024), dim3(256), 0, h->stream, (const int32_t *)a.res_q, (const int32_t *)a.res_c, (const float *)a.res_s,
+                         (const unsigned long long *)(h->counters.p + kCtrPre), (uint64_t)a.res_cap, a.merge_log2, nq, q_ext, (const int64_t *)h->ext.p,
+                         h->res2_q.p, h->res2_c.p, h->res2_s.p, h->counters.p + kCtrResults);
+      HIPCHK(h, hipGetLastError());
+      std::swap(h->res_q, h->res2_q);
+      std::swap(h->res_c, h->res2_c);
+      std::swap(h->res_s, h->res2_s);
+      a.res_q = h->res_q.p;
+      a.res_c = h->res_c.p;
+      a.res_s = h->res_s.p;
+      a.res_cap = std::min(h->res_q.cap, h->res2_q.cap);
+    }
     if (tri) {
       HIPCHK(h, hipMemcpyAsync(h->counters.p + kCtrSnap, h->counters.p + kCtrResults, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
       hipLaunchKernelGGL(k_mirror_survivors, dim3(1024), dim3(256), 0, h->stream, a.res_q, a.res_c, a.res_s,
@@ -2095,7 +2210,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    unsigned long long cc_stack[kCtrCount] = {0, 0, 0, 0, 0, 0}, c_stack[kCtrCount];
+    unsigned long long cc_stack[kCtrCount] = {0, 0, 0, 0, 0, 0, 0}, c_stack[kCtrCount];
     unsigned long long *cc = h->pin ? reinterpret_cast<unsigned long long *>(h->pin + kPinBytes + 64) : cc_stack;
     unsigned long long *c = h->pin ? reinterpret_cast<unsigned long long *>(h->pin + kPinBytes + 128) : c_stack;
     for (int k = 0; k < kCtrCount; ++k) cc[k] = 0;
@@ -2182,6 +2297,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       h->st.candidate_pairs = std::max(h->st.candidate_pairs, h->st.head_pairs);
     }
     h->st.result_pairs = (int64_t)c[kCtrResults];
+    if (a.merge_log2 > 0 && (int64_t)c[kCtrPre] > 2 * nq + 100000) h->merge_off = true;  // (this call's list is right, just long)
     if (cxv.acc8 && (int64_t)c[kCtrResults] > std::max<int64_t>(64 * nq, 4000000)) {
       // the 8-bit filter turned out unselective on this data (skewed terms: chance pairs share dozens of them, and every
       // shared term adds its unit of round-up): correct, but the survivors would swamp the exact pass.  Back to 16-bit
@@ -2485,7 +2601,7 @@ void apss_destroy(apss_handle *h) {
   release(h->q_rowptr); release(h->q_ext); release(h->q_idx); release(h->q_val); release(h->q_sub);
   release(h->s_keep); release(h->s_cnt); release(h->s_rowdst); release(h->s_nnzdst); release(h->scan_tmp);
   release(h->in_rowptr); release(h->in_ext); release(h->in_idx); release(h->s_inv); release(h->s_sub); release(h->in_val); release(h->in_val64); release(h->vq_first); release(h->vrow_q); release(h->vrow_ptr); release(h->vrow_np); release(h->vrow_first);
-  release(h->res_q); release(h->res_c); release(h->res_s); release(h->counters); release(h->flagword); release(h->dbg);
+  release(h->res_q); release(h->res_c); release(h->res_s); release(h->res2_q); release(h->res2_c); release(h->res2_s); release(h->q_prenorm); release(h->counters); release(h->flagword); release(h->dbg);
   release(h->head_pos); release(h->W);
   for (apss_handle::TailView *v : {&h->tv, &h->qtv}) { release(v->rowptr); release(v->idx); release(v->val); release(v->erow); }
   release(h->tv_cnt); release(h->tv_off); release(h->tv_sum); release(h->q_W); release(h->df); release(h->dedup_tab);
@@ -2670,6 +2786,7 @@ int32_t apss_clear(apss_handle *h) {
   h->nonneg = true;
   h->q_nonneg = true;
   h->no_acc8 = h->dbgcfg.no_acc8;
+  h->merge_off = false;
   h->downgrades = 0;
   h->store_max_nnz = 0;
   h->store_max_norm2 = 0.f;

@@ -44,7 +44,10 @@ __device__ __forceinline__ T uniform_load(const T *p) {
 
 // (kCtrDevVisits: posting visits the kernels actually made -- a symmetric whole-store join counts the mirrored half of
 // kCtrVisits / kCtrCands without visiting it; kCtrSnap: the survivor count before k_mirror_survivors appends)
-enum Counter { kCtrResults = 0, kCtrVisits = 1, kCtrCands = 2, kCtrFlags = 3, kCtrDevVisits = 4, kCtrSnap = 5, kCtrCount = 6 };
+// (k_probe_even, merged launches: res_q carries a ROUND, or a query row | kUnmergedBit from a workgroup that ran its rows one per round)
+constexpr int kUnmergedBit = 0x40000000;
+// kCtrPre: the rounds the filter reported before k_expand_merged turned them into pairs
+enum Counter { kCtrResults = 0, kCtrVisits = 1, kCtrCands = 2, kCtrFlags = 3, kCtrDevVisits = 4, kCtrSnap = 5, kCtrPre = 6, kCtrCount = 7 };
 
 // ---------------------------------------------------------------------------------------------------------
 // wavefront ballot / prefix-sum compaction: every active lane with `pred` gets a distinct slot of a global list
@@ -755,6 +758,8 @@ struct ProbeArgs {
   int32_t n_chunks;
   int32_t flat_waves;       // k_probe_even: waves that stage a round = ceil(longest query row / (64 / lanes per term))
   int32_t flat_group_log2;  // k_probe_even: log2 of the staging lanes per term (0, 1 or 2)
+  int32_t merge_log2;       // k_probe_even: 2^merge_log2 neighbouring query rows share a round (apss_even.hpp); nq, q_chunk then count rounds
+  int32_t nq_rows;          //   ... and this is the number of query ROWS (= nq when nothing is merged)
   int32_t tri;              // SYMMETRIC whole-store join (filter kernels): query row v is stored row v and q_chunk divides cb; a
                             // workgroup whose candidate tile lies ABOVE its queries' tile leaves at once, one BELOW counts its
                             // statistics twice, and k_mirror_survivors adds (c, q) for every survivor (q, c) of such a tile pair
@@ -2346,6 +2351,59 @@ __global__ void k_partial_scores(PartialArgs a) {
   }
   for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
   if (gl == 0) a.out[pair] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MERGED rounds of the thin-round filter (apss_even.hpp): M = 2^m neighbouring query rows share a round.
+// k_prenorm_rows: the staged weights divided by their row's shard factor (the kernel otherwise divides per round, by ONE factor);
+// 16 lanes per row.
+__global__ void k_prenorm_rows(const int64_t *rowptr, const float *val, const float *row_scale, int64_t n_rows, float *out) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+  const int gl = threadIdx.x % kGroup;
+  if (row >= n_rows) return;
+  const float sc = row_scale[row];
+  const float inv = sc > 0.f ? 1.0f / sc : 0.f;
+  const int64_t e = rowptr[row + 1];
+  for (int64_t k = rowptr[row] + gl; k < e; k += kGroup) out[k] = val[k] * inv;
+}
+
+// k_expand_merged: the filter reported (round V, candidate c): the SUM of the round's M filter sums crossed the threshold at c.
+// Every query row of the round becomes a survivor (M V + j, c), j < M, except c's own row (self-exclusion by external id,
+// IWA:91, which the kernel left to this pass) -- out of place, into a second list with its own counter.  n_in: the rounds
+// reported (the filter's counter); if it exceeded the list, the out counter is pushed over `cap` too so that the caller's
+// overflow path grows the lists and runs the probe again.
+__global__ void k_expand_merged(const int32_t *in_q, const int32_t *in_c, const float *in_s, const unsigned long long *n_in, uint64_t cap,
+                                int32_t mlog, int64_t nq_rows, const int64_t *q_ext, const int64_t *c_ext, int32_t *out_q, int32_t *out_c,
+                                float *out_s, unsigned long long *counter) {
+  const uint64_t n_rep = (uint64_t)*n_in, n = min(n_rep, cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_rep > cap) atomicAdd(counter, (n_rep - cap) << mlog);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += stride) {  // (uniform per workgroup: wave_append)
+    const uint64_t i = base + threadIdx.x;
+    int64_t q0 = 0;
+    int32_t c = 0;
+    float sc = 0.f;
+    int64_t cext = 0;
+    bool one = false;  // a pair already: reported by a workgroup that ran its rows one per round (self-exclusion done there)
+    if (i < n) {
+      const int32_t rq = in_q[i];
+      one = (rq & kUnmergedBit) != 0;
+      q0 = one ? (int64_t)(rq & ~kUnmergedBit) : (int64_t)rq << mlog;
+      c = in_c[i];
+      sc = in_s[i];
+      cext = c_ext[c];
+    }
+    for (int j = 0; j < (1 << mlog); ++j) {
+      const int64_t q = q0 + j;
+      const bool ok = i < n && q < nq_rows && (one ? j == 0 : q_ext[q] != cext);
+      const uint64_t o = wave_append(ok, counter);
+      if (ok && o < cap) {
+        out_q[o] = (int32_t)q;
+        out_c[o] = c;
+        out_s[o] = sc;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -638,7 +638,8 @@ def main():
                           "build_ms": eng.stats["build_ms"], "posting_visits": eng.stats["posting_visits"], "device_posting_visits": eng.stats["device_posting_visits"],
                           "candidates": int(n_c), "probe_kernel": eng.stats["probe_kernel"], "head_terms": eng.stats["head_terms"],
                           "head_ms": eng.stats["head_ms"], "head_survivors": eng.stats["head_survivors"],
-                          "head_int8": eng.stats["head_int8"],
+                          "head_int8": eng.stats["head_int8"], "queries_per_round": eng.stats.get("queries_per_round"),
+                          "filter_survivors": eng.stats["filter_survivors"],
                           "head_frac_of_mfma_peak": (eng.stats["head_flops"] / (eng.stats["head_ms"] * 1e-3) / 1e12 / (MFMA_I8_PEAK_TOPS if eng.stats["head_int8"] else MFMA_BF16_PEAK_TFLOPS)
                                                      if eng.stats["head_ms"] > 0 else None),
                           "algorithmic_frac": BYTES_PER_VISIT * eng.stats["device_posting_visits"] / (eng.stats["probe_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}))

@@ -123,6 +123,12 @@ typedef struct apss_stats {
   int32_t filter_tile_rows; /* candidate rows per tile of the index rendering the last probe ran over */
   int32_t head_int8;        /* 1: the dense-head block's rows are the INT8 rendering (rounded up; v_mfma_i32_32x32x32_i8: head_flops are
                                integer operations then, against twice the bf16 peak), 0: bf16 */
+  int32_t queries_per_round; /* thin-round filter of a term shard: query rows that SHARED a round of the last probe launch (1 | 2 | 4).
+                                M neighbouring rows are staged as one row and a candidate's accumulator holds the sum of their M
+                                filter sums -- an upper bound of each (non-negative weights), so the filter stays sound; a crossing
+                                becomes M survivors, pruned by the exact scores as ever.  candidate_pairs then counts a candidate
+                                touched by several rows of one round once: a lower bound */
+  int32_t reserved0;
 } apss_stats;
 
 /* apss_stats.symmetric_declined */

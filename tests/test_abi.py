@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(so):
 
 def test_config_struct_matches_header():
     assert ctypes.sizeof(_lib.Config) == 64
-    assert ctypes.sizeof(_lib.Stats) == 280
+    assert ctypes.sizeof(_lib.Stats) == 288
     assert ctypes.sizeof(_lib.GroupStats) == 424
 
 
