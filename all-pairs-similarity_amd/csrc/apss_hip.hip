@@ -2001,10 +2001,12 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   // hit once, by one row.  Rows of three or four terms over a few hundred: three chance hits from different rows of a round
   // cross the threshold (measured: 8 x more candidates than unmerged) -- not there.  A fuse behind the estimate: a merged
   // launch that reports more than two rounds per query row turns merging off for the handle (merge_off).
+  // (Term shards only, with or without a dense-head block -- power-law C5's 8 x 1 shard at N = 2M: tail filter 39.5 -> 24.0 ms.  The
+  // sparse half of a PLAIN handle with a block was tried: its rounds take 4-5 window steps, two rows do not fit one window.)
   const double t_shard = (double)s_nnz_end / (double)std::max<int64_t>(nq, 1);
   const double r_shard = (double)std::max<int64_t>(1, (int64_t)h->cfg.term_hi - h->cfg.term_lo);
   int max_merge_log2 = 0;
-  if (coarse_path && h->sharded && !hybrid_wanted && mode == 0 && !cx_signed && dbg.merge != 0 && !h->merge_off && t_shard >= 8.0)
+  if (coarse_path && h->sharded && mode == 0 && !cx_signed && dbg.merge != 0 && !h->merge_off && t_shard >= 8.0)
     while (max_merge_log2 < (dbg.merge > 0 ? std::min(dbg.merge, 2) : 1) && (nq >> (max_merge_log2 + 1)) >= 1 &&
            (double)(2 << max_merge_log2) * t_shard * t_shard <= 0.25 * r_shard && merged_scale(max_merge_log2 + 1) > 0)
       ++max_merge_log2;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 evidence beyond the headline workload (run on the GPU box from the repo root, via gpurun): bench lines of the other
 # workloads, the streaming and latency harnesses, the full-size properties, one-shard-alone timings and the group rehearsal.
-#   bash profiles/collect_r04_extra.sh part1|part2|part3
+#   bash profiles/collect_r04_extra.sh part1|part2|part3|part4
 set -o pipefail
 OUT=gpurun_out/r04/final; mkdir -p $OUT
 P=${1:-part1}
@@ -34,4 +34,15 @@ if [ "$P" = part3 ]; then
   bash profiles/collect_r04.sh c3z1 > $OUT/collect_c3z1.log 2>&1; echo "collect c3z1 rc=$?"
   bash profiles/head_counters_r04.sh c5z i8final > $OUT/headctr_i8.log 2>&1; echo "headctr rc=$?"
   bash profiles/head_counters_r04.sh c5z bf16 APSS_DEBUG=head_bf16 > $OUT/headctr_bf16.log 2>&1; echo "headctr bf16 rc=$?"
+fi
+if [ "$P" = part4 ]; then
+  # after the merged rounds of the term shards (k_probe_even_merged): the T x 1 shards alone, the group rehearsals, and the headline
+  # line once more now that profiles/r04_probe_traffic.json carries this source tree's hash (bench.py quotes the counters again)
+  : > $OUT/solo_merge.jsonl
+  for s in 4,1,0,0 8,1,0,0 8,1,7,0; do python3 bench.py --solo $s --steps 3 2>/dev/null | line >> $OUT/solo_merge.jsonl; done
+  for s in 8,1,0,0 8,1,7,0; do python3 bench.py --workload c5z --solo $s --steps 2 2>/dev/null | line | sed 's/"solo_shard": "/"solo_shard": "c5z:/' >> $OUT/solo_merge.jsonl; done
+  echo "solo rc=$?"
+  python3 bench.py --gpus 4 --engine group --share-device --steps 3 --warmup 1 --cpu-seconds 2 2> $OUT/group4.err | line > $OUT/group4_c3.json; echo "group4 rc=$?"
+  python3 bench.py --gpus 8 --engine group --share-device --steps 3 --warmup 1 --cpu-seconds 2 2> $OUT/group8.err | line > $OUT/group8_c3.json; echo "group8 rc=$?"
+  python3 bench.py --steps 5 --warmup 1 2> $OUT/bench_c3_again.err | line > $OUT/bench_c3_again.json; echo "c3 rc=$?"
 fi

@@ -110,3 +110,28 @@ def test_rows_of_few_terms_are_not_merged(oracle):
     q, c, s, _ = join_shards_local(engines, n, theta)
     assert_same_pairs(to_map(q, c, s), want, theta)
     assert [e.stats["queries_per_round"] for e in engines] == [1] * 8
+
+
+@pytest.mark.parametrize("T,zipf", [(2, 0.0), (4, 0.0), (4, 1.0)])
+def test_merged_rounds_on_term_shards_with_a_dense_head_block(oracle, T, zipf):
+    """term shards that share a dense-head block (64 terms): the shards' TAIL rounds are the thin ones (power-law C5's 8 x 1
+    shard at N = 2M: tail filter 39.5 -> 24.0 ms with two rows per round); same list as the oracle.  On the small Zipf(1)
+    case the tail keeps long segments and the all-wave kernel: nothing is merged there, the list is the same"""
+    import torch
+    from apss.dist import HipShardEngine, join_shards_local, term_ranges
+    n, dim, nnz, theta = 24_000, 80_000, 80, 0.7
+    rp, idx, val = synth.make_vectors(n, dim, nnz, zipf, seed=4242 + T, dup_frac=0.08)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    assert len(want) > 1000
+    dev = torch.device("cuda", 0)
+    df = np.bincount(idx, minlength=dim)
+    head_terms = np.lexsort((np.arange(dim), -df))[:64].astype(np.int32)
+    df = df.copy()
+    df[head_terms] = 0
+    engines = [HipShardEngine(dim, theta, tr, dev, tile_rows=2048, head=(head_terms, i, T, 0)) for i, tr in enumerate(term_ranges(df, T))]
+    for e in engines:
+        e.load(rp, idx, val)
+    q, c, s, _ = join_shards_local(engines, n, theta)
+    assert_same_pairs(to_map(q, c, s), want, theta)
+    assert all(e.stats["head_terms"] == 64 for e in engines)
+    assert [e.stats["queries_per_round"] for e in engines] == [2 if zipf == 0.0 else 1] * T, [e.stats["probe_kernel"] for e in engines]
