@@ -31,6 +31,8 @@ decides (the library's own policy on a sample of the rows) and broadcasts the te
 The compute engine is injected so the host logic can be exercised on CPU with gloo in tests (tests/ provides an
 engine backed by the CPU oracle); the product engine below is HIP-only.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -348,6 +350,10 @@ class ShardedJoin:
             self.tail_terms_per_row_and_shard = float(df.sum()) / max(1, len(rp) - 1) / self.T
         self.ranges = term_ranges(df, self.T)
         self.term_range = self.ranges[self.ti]
+        # the partition rule's figures: postings and posting visits (sum df, sum df^2) of every term range
+        d64 = df.astype(np.int64)
+        self.range_df = [int(d64[lo:hi].sum()) for lo, hi in self.ranges]
+        self.range_df2 = [int((d64[lo:hi] ** 2).sum()) for lo, hi in self.ranges]
         self.n = len(rp) - 1
         self.row_range = (self.n * self.dj // self.D, self.n * (self.dj + 1) // self.D)
         if self.head.size:
@@ -395,6 +401,7 @@ class ShardedJoin:
         phases = eng.phases() if phased else ("all",)
         out_q, out_c, out_s = [], [], []
         mine, sizes_all, union_all = 0.0, [], 0
+        exchange_s = 0.0
         for ph in phases:
             mirrored = ph == "outside"  # the pairs of this phase stand for both directions (half_spans)
             if phased:
@@ -416,7 +423,13 @@ class ShardedJoin:
                 part = torch.as_tensor(sc, dtype=torch.float32, device=self.device) if sc is not None else partial(uq, uc)
                 keep = torch.ones(q.numel(), dtype=torch.bool, device=self.device) if sc is not None else part >= self.theta
             else:
+                if torch.device(self.device).type == "cuda":
+                    torch.cuda.synchronize(self.device)  # (the handle's kernels are done: what follows is the exchange's own time)
+                t_ex = time.perf_counter()
                 uq, uc, part, keep, sizes, n_union = self._exchange(q, c, partial)
+                if torch.device(self.device).type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                exchange_s += time.perf_counter() - t_ex
             sizes_all += sizes
             union_all += n_union
             mine += (2.0 if mirrored else 1.0) * float(keep.sum().item()) if self.ti == 0 else 0.0
@@ -436,6 +449,16 @@ class ShardedJoin:
                             float(st.get("device_posting_visits", st.get("posting_visits", 0)))], dtype=torch.float64, device=self.comm)
         if self.world > 1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        # what every rank visited (the realised balance of the partition: term ranges are cut by sum df^2, row ranges by rows)
+        mine_v = torch.tensor([float(st.get("device_posting_visits", st.get("posting_visits", 0)))], dtype=torch.float64, device=self.comm)
+        per_rank = [torch.zeros_like(mine_v) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(per_rank, mine_v)
+        else:
+            per_rank = [mine_v]
+        per_rank = [float(x.item()) for x in per_rank]
+        gathered = 8 * max(sizes_all + [1]) * self.T if self.T > 1 else 0
+        reduced = 4 * union_all if self.T > 1 else 0
         self.last = {
             "probe_ms": st.get("probe_ms", 0.0), "build_ms": st.get("build_ms", 0.0), "thin_launches": st.get("thin_launches", 0),
             "probe_kernel": st.get("probe_kernel", ""), "head_ms": st.get("head_ms", 0.0), "head_flops": st.get("head_flops", 0.0),
@@ -443,8 +466,16 @@ class ShardedJoin:
             "posting_visits": int(tot[0].item()), "candidate_pairs": int(tot[1].item()), "device_posting_visits": int(tot[3].item()),
             "exchange": {"term_shards": self.T, "candidate_ranges": self.D, "candidates_per_rank": sizes_all,
                          "union": union_all,
-                         "all_gather_bytes_per_rank": 8 * max(sizes_all + [1]) * self.T if self.T > 1 else 0,
-                         "all_reduce_bytes": 4 * union_all if self.T > 1 else 0, "term_ranges": self.ranges,
+                         "all_gather_bytes_per_rank": gathered, "all_reduce_bytes": reduced, "term_ranges": self.ranges,
+                         "sum_df_per_term_range": self.range_df, "sum_df2_per_term_range": self.range_df2,
+                         "sum_df2_imbalance_max_over_mean": (max(self.range_df2) * len(self.range_df2) / max(1, sum(self.range_df2))),
+                         "device_posting_visits_per_rank": per_rank,
+                         "visits_imbalance_max_over_mean": (max(per_rank) * len(per_rank) / sum(per_rank) if sum(per_rank) > 0 else 1.0),
+                         # this rank's wall time of the exchange steps (all-gather of the lists, sorted union, partial scores,
+                         # all-reduce, threshold) and the bytes it received + reduced over that time: an EFFECTIVE rate of the
+                         # whole exchange, well below a link's wire rate (the collectives are latency-bound at these sizes)
+                         "exchange_ms": exchange_s * 1e3,
+                         "exchange_effective_GBps": ((gathered * (self.T - 1) / max(1, self.T) + 2 * reduced) / exchange_s / 1e9 if exchange_s > 0 else None),
                          "tail_terms_per_row_and_shard": self.tail_terms_per_row_and_shard,
                          "symmetric_row_ranges": bool(self.D > 1 and len(phases) > 1)},
         }

@@ -40,6 +40,13 @@ def _worker(rank, world, port, out_dir, term_shards, head_k=0):
         assert float(abs(sj.engine.xt[:, [t - sj.term_range[0] for t in sj.head if sj.term_range[0] <= t < sj.term_range[1]]]).sum()) == 0.0
     q, c, s = sj.step(return_pairs=True)
     total = sj.step()
+    # the partition rule's figures ride along in `last`: sum df / sum df^2 per term range, what every rank visited,
+    # the exchange's bytes and this rank's time in it
+    ex = sj.last["exchange"]
+    assert len(ex["sum_df_per_term_range"]) == len(ex["sum_df2_per_term_range"]) == term_shards
+    assert len(ex["device_posting_visits_per_rank"]) == world and ex["visits_imbalance_max_over_mean"] >= 1.0 - 1e-9
+    assert ex["sum_df2_imbalance_max_over_mean"] >= 1.0 - 1e-9
+    assert (ex["exchange_ms"] > 0 and ex["exchange_effective_GBps"] > 0) == (term_shards > 1)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), q=q, c=c, s=s, lo=sj.term_range[0], hi=sj.term_range[1],
              union=sj.last["exchange"]["union"], r0=sj.row_range[0], r1=sj.row_range[1], total=total)
     dist.destroy_process_group()
