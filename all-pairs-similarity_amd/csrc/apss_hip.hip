@@ -65,6 +65,7 @@ struct DebugCfg {
   int res_cap = 0;             // res_cap=N      initial capacity of the candidate list (tests of the overflow -> regrow -> re-run path)
   bool head_bf16 = false;      // head_bf16      the dense-head block keeps bf16 rows (v_mfma_f32_32x32x16_bf16), never the INT8 rendering
   int merge = -1;              // merge=L        a term shard's thin rounds: at most 2^L query rows share a round (0: never; default 1: two rows)
+  bool no_merge_prune = false; // no_merge_prune merged rounds hand every expanded pair to the exchange (no exact shard-rule test behind k_expand_merged)
   int merge_u = 0;             // merge_u=U      ... as long as the merged round fits a window of U steps (default 7)
   int merge_single = 0;        // merge_single=U ... and a single row's round takes a window of at most U steps (default 4)
 };
@@ -114,6 +115,7 @@ DebugCfg parse_debug_env() {
     else if (key == "bucket_range") d.bucket_range = val;
     else if (key == "merge") d.merge = (int)val;
     else if (key == "merge_u") d.merge_u = (int)val;
+    else if (key == "no_merge_prune") d.no_merge_prune = val != 0;
     else if (key == "merge_single") d.merge_single = (int)val;
     else if (!key.empty()) fprintf(stderr, "[apss] unknown APSS_DEBUG token '%s' ignored\n", key.c_str());
   }
@@ -2191,9 +2193,8 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       }
     }  // tile groups
     if (a.merge_log2 > 0) {  // (round, candidate) -> the round's (query row, candidate) pairs
-      HIPCHK(h, hipMemcpyAsync(h->counters.p + kCtrPre, h->counters.p + kCtrResults, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
-      HIPCHK(h, hipMemsetAsync(h->counters.p + kCtrResults, 0, sizeof(unsigned long long), h->stream));
-      hipLaunchKernelGGL(k_expand_merged, dim3(1024), dim3(256), 0, h->stream, (const int32_t *)a.res_q, (const int32_t *)a.res_c, (const float *)a.res_s,
+      hipLaunchKernelGGL(k_counter_move, dim3(1), dim3(1), 0, h->stream, h->counters.p, (int)kCtrResults, (int)kCtrPre);
+      hipLaunchKernelGGL(k_expand_merged, dim3((unsigned)std::min<int64_t>(1024, ceil_div(nq / 4 + 4096, 256))), dim3(256), 0, h->stream, (const int32_t *)a.res_q, (const int32_t *)a.res_c, (const float *)a.res_s,
                          (const unsigned long long *)(h->counters.p + kCtrPre), (uint64_t)a.res_cap, a.merge_log2, nq, q_ext, (const int64_t *)h->ext.p,
                          h->res2_q.p, h->res2_c.p, h->res2_s.p, h->counters.p + kCtrResults);
       HIPCHK(h, hipGetLastError());
@@ -2204,6 +2205,40 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       a.res_c = h->res_c.p;
       a.res_s = h->res_s.p;
       a.res_cap = std::min(h->res_q.cap, h->res2_q.cap);
+      if (h->sharded && !dbg.no_merge_prune) {
+        // ... and only those of them that pass the shard rule on their EXACT partial score stay (k_shard_prune): the exchange
+        // gets no more candidates than without merging
+        hipLaunchKernelGGL(k_counter_move, dim3(1), dim3(1), 0, h->stream, h->counters.p, (int)kCtrResults, (int)kCtrPre);
+        ShardPruneArgs sp{};
+        sp.in_q = h->res_q.p;
+        sp.in_c = h->res_c.p;
+        sp.in_s = h->res_s.p;
+        sp.n_in = h->counters.p + kCtrPre;
+        sp.cap = a.res_cap;
+        sp.q_rowptr = s_rowptr;
+        sp.q_idx = s_idx;
+        sp.q_val = s_val;
+        sp.q_sub = q_sub;
+        sp.c_rowptr = h->head_k ? h->tv.rowptr.p : h->rowptr.p;
+        sp.c_idx = h->head_k ? h->tv.idx.p : h->idx.p;
+        sp.c_val = h->head_k ? h->tv.val.p : h->val.p;
+        sp.c_sub = h->sub.p;
+        sp.theta = (float)theta;
+        sp.out_q = h->res2_q.p;
+        sp.out_c = h->res2_c.p;
+        sp.out_s = h->res2_s.p;
+        sp.counter = h->counters.p + kCtrResults;
+        // (a grid for what a shard usually reports -- a fraction of a pair per query row; the kernel strides over whatever the counter holds)
+        const int64_t grid_pairs = std::min<int64_t>((int64_t)a.res_cap, nq / 4 + 4096);
+        hipLaunchKernelGGL(k_shard_prune, dim3((unsigned)std::min<int64_t>(4096, ceil_div(grid_pairs * kGroup, 256))), dim3(256), 0, h->stream, sp);
+        HIPCHK(h, hipGetLastError());
+        std::swap(h->res_q, h->res2_q);
+        std::swap(h->res_c, h->res2_c);
+        std::swap(h->res_s, h->res2_s);
+        a.res_q = h->res_q.p;
+        a.res_c = h->res_c.p;
+        a.res_s = h->res_s.p;
+      }
     }
     if (tri) {
       HIPCHK(h, hipMemcpyAsync(h->counters.p + kCtrSnap, h->counters.p + kCtrResults, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
@@ -2299,7 +2334,9 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       h->st.candidate_pairs = std::max(h->st.candidate_pairs, h->st.head_pairs);
     }
     h->st.result_pairs = (int64_t)c[kCtrResults];
-    if (a.merge_log2 > 0 && (int64_t)c[kCtrPre] > 2 * nq + 100000) h->merge_off = true;  // (this call's list is right, just long)
+    // (kCtrPre: the rounds the filter reported, or -- with the shard-rule test behind it -- the pairs they expanded to)
+    if (a.merge_log2 > 0 && (int64_t)c[kCtrPre] > (2 * nq + 100000) * (h->sharded && !dbg.no_merge_prune ? (1LL << a.merge_log2) : 1LL))
+      h->merge_off = true;  // (this call's list is right, the filter just passed too much)
     if (cxv.acc8 && (int64_t)c[kCtrResults] > std::max<int64_t>(64 * nq, 4000000)) {
       // the 8-bit filter turned out unselective on this data (skewed terms: chance pairs share dozens of them, and every
       // shared term adds its unit of round-up): correct, but the survivors would swamp the exact pass.  Back to 16-bit

@@ -2406,6 +2406,77 @@ __global__ void k_expand_merged(const int32_t *in_q, const int32_t *in_c, const 
   }
 }
 
+// (one launch instead of a device-to-device copy and a fill: counters[to] = counters[from], counters[from] = 0)
+__global__ void k_counter_move(unsigned long long *counters, int from, int to) {
+  counters[to] = counters[from];
+  counters[from] = 0ull;
+}
+
+// k_shard_prune: behind k_expand_merged on a term shard.  A crossing of a merged round stands for every row of the round, so
+// half of the expanded pairs (M = 2) are there for their neighbour's sake.  Each pair's EXACT partial score over the shard's
+// rows (two sorted index lists, 16 lanes per pair, as k_partial_scores) is tested against the shard rule itself,
+//   p_g >= theta * r_q * r_c   (r = |x_g| / |x|: what the filter's normalised sums are an upper bound of),
+// with a relative slack of 1e-4 for the fp32 sum (a pair >= theta overall satisfies the rule in at least one shard --
+// Cauchy-Schwarz over the shards -- passes that shard's filter, and stays here).  What the shard hands to the exchange is then
+// no longer than without merging.  Out of place, as k_expand_merged; an overflowed input keeps the counter above `cap`.
+struct ShardPruneArgs {
+  const int32_t *in_q, *in_c;
+  const float *in_s;
+  const unsigned long long *n_in;
+  uint64_t cap;
+  const int64_t *q_rowptr;  // the staged query rows (the shard's slice; the tail view on a shard with a dense-head block)
+  const int32_t *q_idx;
+  const float *q_val;
+  const float *q_sub;
+  const int64_t *c_rowptr;  // the indexed rows, by slot
+  const int32_t *c_idx;
+  const float *c_val;
+  const float *c_sub;
+  float theta;
+  int32_t *out_q, *out_c;
+  float *out_s;
+  unsigned long long *counter;
+};
+
+__global__ void k_shard_prune(ShardPruneArgs a) {
+  const int gl = threadIdx.x % kGroup;
+  const uint64_t n_rep = (uint64_t)*a.n_in, n = min(n_rep, a.cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_rep > a.cap) atomicAdd(a.counter, n_rep);
+  const uint64_t groups = (uint64_t)gridDim.x * blockDim.x / kGroup;
+  const int sub = (threadIdx.x % kWave) / kGroup;
+  for (uint64_t wb = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup - sub; wb < n; wb += groups) {  // wave-uniform
+    const uint64_t pair = wb + sub;
+    const bool live = pair < n;
+    float s = 0.f, bound = 0.f, sc = 0.f;
+    int32_t qr = 0, cs = 0;
+    if (live) {
+      qr = a.in_q[pair];
+      cs = a.in_c[pair];
+      sc = a.in_s[pair];
+      bound = a.theta * (1.0f - 1e-4f) * a.q_sub[qr] * a.c_sub[cs];
+      const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
+      const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
+      for (int64_t k = qb + gl; k < qe; k += kGroup) {
+        const int32_t t = a.q_idx[k];
+        int64_t lo = cb, hi = ce;
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+        }
+        if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
+      }
+    }
+    for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
+    const bool keep = live && gl == 0 && s > 0.f && s >= bound;
+    const uint64_t o = wave_append(keep, a.counter);
+    if (keep && o < a.cap) {
+      a.out_q[o] = qr;
+      a.out_c[o] = cs;
+      a.out_s[o] = sc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_mirror_survivors: the second half of a SYMMETRIC whole-store join (ProbeArgs::tri).  The filter kernels skipped every
 // workgroup whose candidate tile lies above its queries' tile; a survivor (q, c) with c's tile BELOW q's tile stands for the

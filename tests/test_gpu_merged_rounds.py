@@ -135,3 +135,27 @@ def test_merged_rounds_on_term_shards_with_a_dense_head_block(oracle, T, zipf):
     assert_same_pairs(to_map(q, c, s), want, theta)
     assert all(e.stats["head_terms"] == 64 for e in engines)
     assert [e.stats["queries_per_round"] for e in engines] == [2 if zipf == 0.0 else 1] * T, [e.stats["probe_kernel"] for e in engines]
+
+
+def test_merged_rounds_hand_over_no_more_candidates_than_unmerged(oracle, monkeypatch):
+    """a crossing of a merged round stands for both of its rows; k_shard_prune keeps the pairs that pass the shard rule on their EXACT
+    partial score, so the list a shard hands to the exchange is no longer than the unmerged filter's (whose sums are upper
+    bounds) -- and without that test (no_merge_prune) it is up to twice as long; the joined result is the same in all three"""
+    import torch
+    from apss.dist import HipShardEngine, join_shards_local, term_ranges
+    n, dim, nnz, theta, world = 20_000, 60_000, 64, 0.7, 4
+    rp, idx, val = _data(n, dim, nnz, seed=515)
+    want = to_map(*oracle.selfjoin_pairs(dim, theta, rp, idx, val))
+    dev = torch.device("cuda", 0)
+    ranges = term_ranges(np.bincount(idx, minlength=dim), world)
+    cands = {}
+    for hook in ("merge=0", "merge=1", "merge=1,no_merge_prune"):
+        monkeypatch.setenv("APSS_DEBUG", hook)  # read when a handle is created
+        engines = [HipShardEngine(dim, theta, tr, dev, tile_rows=1024) for tr in ranges]
+        for e in engines:
+            e.load(rp, idx, val)
+        q, c, s, n_cand = join_shards_local(engines, n, theta)
+        assert_same_pairs(to_map(q, c, s), want, theta)
+        assert [e.stats["queries_per_round"] for e in engines] == [1 if hook == "merge=0" else 2] * world
+        cands[hook] = sum(n_cand)
+    assert cands["merge=1"] <= cands["merge=0"] < cands["merge=1,no_merge_prune"] <= 2 * cands["merge=0"] + 100, cands
