@@ -2196,7 +2196,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       hipLaunchKernelGGL(k_counter_move, dim3(1), dim3(1), 0, h->stream, h->counters.p, (int)kCtrResults, (int)kCtrPre);
       hipLaunchKernelGGL(k_expand_merged, dim3((unsigned)std::min<int64_t>(1024, ceil_div(nq / 4 + 4096, 256))), dim3(256), 0, h->stream, (const int32_t *)a.res_q, (const int32_t *)a.res_c, (const float *)a.res_s,
                          (const unsigned long long *)(h->counters.p + kCtrPre), (uint64_t)a.res_cap, a.merge_log2, nq, q_ext, (const int64_t *)h->ext.p,
-                         h->res2_q.p, h->res2_c.p, h->res2_s.p, h->counters.p + kCtrResults);
+                         h->res2_q.p, h->res2_c.p, h->res2_s.p, h->counters.p + kCtrResults, h->counters.p + kCtrOver);
       HIPCHK(h, hipGetLastError());
       std::swap(h->res_q, h->res2_q);
       std::swap(h->res_c, h->res2_c);
@@ -2228,6 +2228,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
         sp.out_c = h->res2_c.p;
         sp.out_s = h->res2_s.p;
         sp.counter = h->counters.p + kCtrResults;
+        sp.over = h->counters.p + kCtrOver;
         // (a grid for what a shard usually reports -- a fraction of a pair per query row; the kernel strides over whatever the counter holds)
         const int64_t grid_pairs = std::min<int64_t>((int64_t)a.res_cap, nq / 4 + 4096);
         hipLaunchKernelGGL(k_shard_prune, dim3((unsigned)std::min<int64_t>(4096, ceil_div(grid_pairs * kGroup, 256))), dim3(256), 0, h->stream, sp);
@@ -2247,7 +2248,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    unsigned long long cc_stack[kCtrCount] = {0, 0, 0, 0, 0, 0, 0}, c_stack[kCtrCount];
+    unsigned long long cc_stack[kCtrCount] = {0, 0, 0, 0, 0, 0, 0, 0}, c_stack[kCtrCount];
     unsigned long long *cc = h->pin ? reinterpret_cast<unsigned long long *>(h->pin + kPinBytes + 64) : cc_stack;
     unsigned long long *c = h->pin ? reinterpret_cast<unsigned long long *>(h->pin + kPinBytes + 128) : c_stack;
     for (int k = 0; k < kCtrCount; ++k) cc[k] = 0;
@@ -2348,9 +2349,10 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       APSS_TRY(build_index(h, 0));
       return probe(h, nq, q_rowptr, q_idx, q_val, q_ext, q_slot_first, q_max_nnz, q_max_norm2, q_nnz_end, n_results);
     }
-    if (c[kCtrResults] > a.res_cap) {
-      // the result list overflowed: grow to what the run asked for and repeat the (idempotent) probe
-      size_t need = (size_t)c[kCtrResults] + (size_t)c[kCtrResults] / 8 + 1024;
+    if (std::max(c[kCtrResults], c[kCtrOver]) > a.res_cap) {
+      // the result list overflowed (or a list on the way to it did: kCtrOver): grow to what the run asked for and repeat the (idempotent) probe
+      const size_t asked = (size_t)std::max(c[kCtrResults], c[kCtrOver]);
+      size_t need = asked + asked / 8 + 1024;
       if (tri) {
         // a symmetric run whose FILTER overflowed mirrored only what the list held: the counter under-reports.  What the run
         // needs is known all the same: the filter's own count (kCtrSnap, taken before the mirror) twice over, plus what the

@@ -46,8 +46,10 @@ __device__ __forceinline__ T uniform_load(const T *p) {
 // kCtrVisits / kCtrCands without visiting it; kCtrSnap: the survivor count before k_mirror_survivors appends)
 // (k_probe_even, merged launches: res_q carries a ROUND, or a query row | kUnmergedBit from a workgroup that ran its rows one per round)
 constexpr int kUnmergedBit = 0x40000000;
-// kCtrPre: the rounds the filter reported before k_expand_merged turned them into pairs
-enum Counter { kCtrResults = 0, kCtrVisits = 1, kCtrCands = 2, kCtrFlags = 3, kCtrDevVisits = 4, kCtrSnap = 5, kCtrPre = 6, kCtrCount = 7 };
+// kCtrPre: the rounds the filter reported before k_expand_merged turned them into pairs; kCtrOver: the list capacity that
+// k_expand_merged / k_shard_prune would have needed when their INPUT list had overflowed (a maximum, in a counter of its own:
+// added to kCtrResults it would shift the slots the kernels hand out, and the list's first `cap` entries would stay unwritten)
+enum Counter { kCtrResults = 0, kCtrVisits = 1, kCtrCands = 2, kCtrFlags = 3, kCtrDevVisits = 4, kCtrSnap = 5, kCtrPre = 6, kCtrOver = 7, kCtrCount = 8 };
 
 // ---------------------------------------------------------------------------------------------------------
 // wavefront ballot / prefix-sum compaction: every active lane with `pred` gets a distinct slot of a global list
@@ -2370,13 +2372,13 @@ __global__ void k_prenorm_rows(const int64_t *rowptr, const float *val, const fl
 // k_expand_merged: the filter reported (round V, candidate c): the SUM of the round's M filter sums crossed the threshold at c.
 // Every query row of the round becomes a survivor (M V + j, c), j < M, except c's own row (self-exclusion by external id,
 // IWA:91, which the kernel left to this pass) -- out of place, into a second list with its own counter.  n_in: the rounds
-// reported (the filter's counter); if it exceeded the list, the out counter is pushed over `cap` too so that the caller's
-// overflow path grows the lists and runs the probe again.
+// reported (the filter's counter); if it exceeded the list, `over` (kCtrOver) is raised to the capacity that holds all of them
+// expanded, so that the caller's overflow path grows the lists and runs the probe again.
 __global__ void k_expand_merged(const int32_t *in_q, const int32_t *in_c, const float *in_s, const unsigned long long *n_in, uint64_t cap,
                                 int32_t mlog, int64_t nq_rows, const int64_t *q_ext, const int64_t *c_ext, int32_t *out_q, int32_t *out_c,
-                                float *out_s, unsigned long long *counter) {
+                                float *out_s, unsigned long long *counter, unsigned long long *over) {
   const uint64_t n_rep = (uint64_t)*n_in, n = min(n_rep, cap);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && n_rep > cap) atomicAdd(counter, (n_rep - cap) << mlog);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_rep > cap) atomicMax(over, (unsigned long long)(n_rep << mlog));
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += stride) {  // (uniform per workgroup: wave_append)
     const uint64_t i = base + threadIdx.x;
@@ -2418,7 +2420,7 @@ __global__ void k_counter_move(unsigned long long *counters, int from, int to) {
 //   p_g >= theta * r_q * r_c   (r = |x_g| / |x|: what the filter's normalised sums are an upper bound of),
 // with a relative slack of 1e-4 for the fp32 sum (a pair >= theta overall satisfies the rule in at least one shard --
 // Cauchy-Schwarz over the shards -- passes that shard's filter, and stays here).  What the shard hands to the exchange is then
-// no longer than without merging.  Out of place, as k_expand_merged; an overflowed input keeps the counter above `cap`.
+// no longer than without merging.  Out of place, as k_expand_merged; an overflowed input is reported through `over`.
 struct ShardPruneArgs {
   const int32_t *in_q, *in_c;
   const float *in_s;
@@ -2436,12 +2438,13 @@ struct ShardPruneArgs {
   int32_t *out_q, *out_c;
   float *out_s;
   unsigned long long *counter;
+  unsigned long long *over;
 };
 
 __global__ void k_shard_prune(ShardPruneArgs a) {
   const int gl = threadIdx.x % kGroup;
   const uint64_t n_rep = (uint64_t)*a.n_in, n = min(n_rep, a.cap);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && n_rep > a.cap) atomicAdd(a.counter, n_rep);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_rep > a.cap) atomicMax(a.over, (unsigned long long)n_rep);
   const uint64_t groups = (uint64_t)gridDim.x * blockDim.x / kGroup;
   const int sub = (threadIdx.x % kWave) / kGroup;
   for (uint64_t wb = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup - sub; wb < n; wb += groups) {  // wave-uniform

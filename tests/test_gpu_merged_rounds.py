@@ -26,7 +26,8 @@ def _data(n, dim, nnz, seed):
     return rp, idx.reshape(-1), val.reshape(-1)
 
 
-@pytest.mark.parametrize("world,tile_rows,merge", [(4, 1024, None), (4, 1024, "merge=1"), (4, 1024, "merge=0"), (8, 0, None), (2, 2048, "merge=2,merge_single=7,merge_u=7")])
+@pytest.mark.parametrize("world,tile_rows,merge", [(4, 1024, None), (4, 1024, "merge=1"), (4, 1024, "merge=0"), (8, 0, None), (2, 2048, "merge=2,merge_single=7,merge_u=7"),
+                                                      (4, 1024, "res_cap=256"), (4, 1024, "res_cap=256,no_merge_prune")])
 def test_merged_rounds_match_oracle(oracle, monkeypatch, world, tile_rows, merge):
     import torch
     if merge:
