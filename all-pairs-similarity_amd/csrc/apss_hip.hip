@@ -1048,7 +1048,7 @@ int32_t head_sample_selectivity(apss_handle *h, double *frac) {
     r.out_c = h->fin_c.p;
     r.out_s = h->fin_s.p;
     r.out_count = h->head_ctr.p;
-    hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(r.n_pairs * kGroup, 256)), dim3(256), 0, h->stream, r);
+    hipLaunchKernelGGL(k_rescore, dim3((unsigned)std::max<int64_t>(1, ceil_div(r.n_pairs, (int64_t)kRescorePairs * kRescoreTrips))), dim3(kRescoreBlock), 0, h->stream, r);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(&n_true, h->head_ctr.p, sizeof(n_true), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1727,7 +1727,7 @@ int32_t exact_pass(apss_handle *h, bool hybrid, double theta, int64_t nq, const 
       rr.n_pairs = std::min<int64_t>(1LL << 27, n_cand - p0);
       rr.q_row = cand_q + p0;
       rr.c_slot = cand_c + p0;
-      hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(rr.n_pairs * kGroup, 256)), dim3(256), 0, h->stream, rr);
+      hipLaunchKernelGGL(k_rescore, dim3((unsigned)std::max<int64_t>(1, ceil_div(rr.n_pairs, (int64_t)kRescorePairs * kRescoreTrips))), dim3(kRescoreBlock), 0, h->stream, rr);
       HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -2231,7 +2231,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
         sp.over = h->counters.p + kCtrOver;
         // (a grid for what a shard usually reports -- a fraction of a pair per query row; the kernel strides over whatever the counter holds)
         const int64_t grid_pairs = std::min<int64_t>((int64_t)a.res_cap, nq / 4 + 4096);
-        hipLaunchKernelGGL(k_shard_prune, dim3((unsigned)std::min<int64_t>(4096, ceil_div(grid_pairs * kGroup, 256))), dim3(256), 0, h->stream, sp);
+        hipLaunchKernelGGL(k_shard_prune, dim3((unsigned)std::min<int64_t>(2048, ceil_div(grid_pairs, kPrunePairs * 4))), dim3(kPruneBlock), 0, h->stream, sp);
         HIPCHK(h, hipGetLastError());
         std::swap(h->res_q, h->res2_q);
         std::swap(h->res_c, h->res2_c);
@@ -2272,7 +2272,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
       r.out_count = h->chain_ctr.p + kCtrResults;
       // (grid for what such a batch usually passes; the kernel strides over whatever the counter holds)
       const int64_t grid_pairs = std::min<int64_t>((int64_t)a.res_cap, 64 * nq + 4096);
-      hipLaunchKernelGGL(k_rescore, dim3((unsigned)ceil_div(grid_pairs * kGroup, 256)), dim3(256), 0, h->stream, r);
+      hipLaunchKernelGGL(k_rescore, dim3((unsigned)std::max<int64_t>(1, ceil_div(grid_pairs, (int64_t)kRescorePairs * kRescoreTrips))), dim3(kRescoreBlock), 0, h->stream, r);
       if (tail_n > 0) {
         TailArgs t{};
         t.nq = nq;

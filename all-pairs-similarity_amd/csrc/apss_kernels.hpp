@@ -2202,40 +2202,60 @@ struct RescoreArgs {
   const unsigned long long *n_pairs_dev;
 };
 
-__global__ void k_rescore(RescoreArgs a) {
-  const int gl = threadIdx.x % kGroup;
+// (The kept pairs of a workgroup's trips are staged in LDS and appended with ONE global atomic per workgroup: a wave-level
+// append is an atomic per wave and trip on one address, and same-address atomics are serialised at the memory side -- see
+// k_shard_prune, where the same change took 295 -> 47 us.)
+constexpr int kRescoreBlock = 512, kRescoreTrips = 1, kRescorePairs = kRescoreBlock / kGroup;  // pairs per workgroup and trip (long rows: a trip is a long chain of dependent loads -- one per workgroup, all pairs in flight at once)
+__global__ __launch_bounds__(kRescoreBlock) void k_rescore(RescoreArgs a) {
+  __shared__ int32_t st_q[kRescorePairs * kRescoreTrips], st_c[kRescorePairs * kRescoreTrips];
+  __shared__ float st_s[kRescorePairs * kRescoreTrips];
+  __shared__ uint32_t st_n;
+  __shared__ unsigned long long st_base;
+  const int tid = threadIdx.x, gl = tid % kGroup, grp = tid / kGroup;
   const int64_t n = a.n_pairs_dev ? min((int64_t)*a.n_pairs_dev, a.n_pairs) : a.n_pairs;
-  const int64_t groups = (int64_t)gridDim.x * blockDim.x / kGroup;
-  const int sub = (threadIdx.x % kWave) / kGroup;  // pair of the wave this lane works on
-  // wave-uniform loop (a grid sized for an upper bound strides over what the counter holds; the usual launch takes one trip)
-  for (int64_t wb = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup - sub; wb < n; wb += groups) {
-    const int64_t pair = wb + sub;
-    const bool live = pair < n;
-    float s = 0.f;
-    int32_t qr = 0, cs = 0;
-    if (live) {
-      qr = a.q_row[pair];
-      cs = a.c_slot[pair];
-      const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
-      const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
-      for (int64_t k = qb + gl; k < qe; k += kGroup) {
-        const int32_t t = a.q_idx[k];
-        int64_t lo = cb, hi = ce;
-        while (lo < hi) {
-          const int64_t mid = (lo + hi) >> 1;
-          if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+  const int64_t stride = (int64_t)gridDim.x * kRescorePairs;
+  // (a grid sized for an upper bound strides over what the counter holds; the usual launch takes one round of trips)
+  for (int64_t base = (int64_t)blockIdx.x * kRescorePairs; base < n; base += stride * kRescoreTrips) {  // uniform per workgroup
+    if (tid == 0) st_n = 0u;
+    __syncthreads();
+    for (int trip = 0; trip < kRescoreTrips; ++trip) {
+      const int64_t pair = base + (int64_t)trip * stride + grp;
+      const bool live = pair < n;
+      float s = 0.f;
+      int32_t qr = 0, cs = 0;
+      if (live) {
+        qr = a.q_row[pair];
+        cs = a.c_slot[pair];
+        const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
+        const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
+        for (int64_t k = qb + gl; k < qe; k += kGroup) {
+          const int32_t t = a.q_idx[k];
+          int64_t lo = cb, hi = ce;
+          while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+          }
+          if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
         }
-        if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
+      }
+      for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
+      if (live && gl == 0 && s >= a.theta) {
+        const uint32_t at = atomicAdd(&st_n, 1u);  // (LDS)
+        st_q[at] = qr;
+        st_c[at] = cs;
+        st_s[at] = s;
       }
     }
-    for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
-    const bool keep = live && gl == 0 && s >= a.theta;
-    const uint64_t o = wave_append(keep, a.out_count);
-    if (keep) {
-      a.out_q[o] = qr;
-      a.out_c[o] = cs;
-      a.out_s[o] = s;
+    __syncthreads();
+    const uint32_t kept = st_n;
+    if (tid == 0 && kept) st_base = atomicAdd(a.out_count, (unsigned long long)kept);
+    __syncthreads();
+    for (uint32_t i = tid; i < kept; i += kRescoreBlock) {
+      a.out_q[st_base + i] = st_q[i];
+      a.out_c[st_base + i] = st_c[i];
+      a.out_s[st_base + i] = st_s[i];
     }
+    __syncthreads();  // (the staging area is reused by the next trips)
   }
 }
 
@@ -2441,42 +2461,65 @@ struct ShardPruneArgs {
   unsigned long long *over;
 };
 
-__global__ void k_shard_prune(ShardPruneArgs a) {
-  const int gl = threadIdx.x % kGroup;
+// (One global atomic per WORKGROUP and sixteen trips, not one per wave and trip: every wave that keeps a pair appends through the
+// same address, and same-address atomics are serialised at the memory side -- rocprofv3 on a T = 8 shard of C3: 295 us for
+// 197k pairs with a wave-level append, i.e. 49k atomics of ~6 ns.  The kept pairs of up to 16 trips are staged in LDS.)
+constexpr int kPruneBlock = 256, kPruneTrips = 16, kPrunePairs = kPruneBlock / kGroup;  // pairs per workgroup and trip
+__global__ __launch_bounds__(kPruneBlock) void k_shard_prune(ShardPruneArgs a) {
+  __shared__ int32_t st_q[kPrunePairs * kPruneTrips], st_c[kPrunePairs * kPruneTrips];
+  __shared__ float st_s[kPrunePairs * kPruneTrips];
+  __shared__ uint32_t st_n;
+  __shared__ unsigned long long st_base;
+  const int tid = threadIdx.x, gl = tid % kGroup, grp = tid / kGroup;
   const uint64_t n_rep = (uint64_t)*a.n_in, n = min(n_rep, a.cap);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && n_rep > a.cap) atomicMax(a.over, (unsigned long long)n_rep);
-  const uint64_t groups = (uint64_t)gridDim.x * blockDim.x / kGroup;
-  const int sub = (threadIdx.x % kWave) / kGroup;
-  for (uint64_t wb = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup - sub; wb < n; wb += groups) {  // wave-uniform
-    const uint64_t pair = wb + sub;
-    const bool live = pair < n;
-    float s = 0.f, bound = 0.f, sc = 0.f;
-    int32_t qr = 0, cs = 0;
-    if (live) {
-      qr = a.in_q[pair];
-      cs = a.in_c[pair];
-      sc = a.in_s[pair];
-      bound = a.theta * (1.0f - 1e-4f) * a.q_sub[qr] * a.c_sub[cs];
-      const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
-      const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
-      for (int64_t k = qb + gl; k < qe; k += kGroup) {
-        const int32_t t = a.q_idx[k];
-        int64_t lo = cb, hi = ce;
-        while (lo < hi) {
-          const int64_t mid = (lo + hi) >> 1;
-          if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+  if (blockIdx.x == 0 && tid == 0 && n_rep > a.cap) atomicMax(a.over, (unsigned long long)n_rep);
+  const uint64_t stride = (uint64_t)gridDim.x * kPrunePairs;
+  for (uint64_t base = (uint64_t)blockIdx.x * kPrunePairs; base < n; base += stride * kPruneTrips) {  // (uniform per workgroup)
+    if (tid == 0) st_n = 0u;
+    __syncthreads();
+    for (int trip = 0; trip < kPruneTrips; ++trip) {
+      const uint64_t pair = base + (uint64_t)trip * stride + (uint64_t)grp;
+      const bool live = pair < n;
+      float s = 0.f, bound = 0.f, sc = 0.f;
+      int32_t qr = 0, cs = 0;
+      if (live) {
+        qr = a.in_q[pair];
+        cs = a.in_c[pair];
+        sc = a.in_s[pair];
+        bound = a.theta * (1.0f - 1e-4f) * a.q_sub[qr] * a.c_sub[cs];
+        const int64_t qb = a.q_rowptr[qr], qe = a.q_rowptr[qr + 1];
+        const int64_t cb = a.c_rowptr[cs], ce = a.c_rowptr[cs + 1];
+        for (int64_t k = qb + gl; k < qe; k += kGroup) {
+          const int32_t t = a.q_idx[k];
+          int64_t lo = cb, hi = ce;
+          while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.c_idx[mid] < t) lo = mid + 1; else hi = mid;
+          }
+          if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
         }
-        if (lo < ce && a.c_idx[lo] == t) s += a.q_val[k] * a.c_val[lo];
+      }
+      for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
+      if (live && gl == 0 && s > 0.f && s >= bound) {
+        const uint32_t at = atomicAdd(&st_n, 1u);  // (LDS)
+        st_q[at] = qr;
+        st_c[at] = cs;
+        st_s[at] = sc;
       }
     }
-    for (int o = kGroup / 2; o; o >>= 1) s += __shfl_xor(s, o, kGroup);
-    const bool keep = live && gl == 0 && s > 0.f && s >= bound;
-    const uint64_t o = wave_append(keep, a.counter);
-    if (keep && o < a.cap) {
-      a.out_q[o] = qr;
-      a.out_c[o] = cs;
-      a.out_s[o] = sc;
+    __syncthreads();
+    const uint32_t kept = st_n;
+    if (tid == 0 && kept) st_base = atomicAdd(a.counter, (unsigned long long)kept);
+    __syncthreads();
+    for (uint32_t i = tid; i < kept; i += kPruneBlock) {
+      const uint64_t o = st_base + i;
+      if (o < a.cap) {
+        a.out_q[o] = st_q[i];
+        a.out_c[o] = st_c[i];
+        a.out_s[o] = st_s[i];
+      }
     }
+    __syncthreads();  // (the staging area is reused by the next sixteen trips)
   }
 }
 
