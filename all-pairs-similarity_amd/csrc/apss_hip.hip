@@ -1366,7 +1366,7 @@ bool cx_variant_exists(const CxVariant &v) {
 }
 
 int32_t launch_cx(apss_handle *h, const CxVariant &v, const ProbeArgs &a) {
- const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
+  const dim3 grid((unsigned)((int64_t)a.n_tiles * a.n_chunks));
   if (v.even && v.merge) {
 #define X(U, A8)                                                                                                           \
     if (v.block == 512 && v.u == U && v.acc8 == A8) {                                                                      \
@@ -1802,6 +1802,7 @@ int32_t probe(apss_handle *h, int64_t nq, const int64_t *q_rowptr, const int32_t
   h->st.probe_ms = 0;
   h->st.probe_launches = 0;
   h->st.thin_launches = 0;
+  h->st.queries_per_round = 1;
   h->st.probe_kernel[0] = 0;
   h->st.head_pairs = h->st.head_survivors = 0;
   h->st.head_ms = h->st.head_flops = 0;

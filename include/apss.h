@@ -113,7 +113,8 @@ typedef struct apss_stats {
   uint32_t head_columns;    /* width of a row of the dense-head block at the last call: 64 | 128 | 256 (0: none) */
   char probe_kernel[96];    /* the probe kernel instantiation the last query-type call launched, as rocprofv3 prints its name up
                                to the template arguments' spelling, e.g. "k_probe_even<512, 6, 128, false, false, false>" (threads, window steps,
-                               long-segment list, shard rule, signed, 8-bit accumulators); "" before any probe */
+                               long-segment list, shard rule, signed, 8-bit accumulators) or "k_probe_even_merged<4, true>" (a term shard's rounds
+                               with two query rows each: window steps, 8-bit accumulators; queries_per_round); "" before any probe */
   int64_t device_posting_visits; /* posting visits the kernels of the last call actually made: equal to posting_visits except
                                     on a symmetric whole-store join, where posting_visits / candidate_pairs keep counting what
                                     the reference's two-directional probe visits and the device visits about half of it */
@@ -126,8 +127,9 @@ typedef struct apss_stats {
   int32_t queries_per_round; /* thin-round filter of a term shard: query rows that SHARED a round of the last probe launch (1 | 2 | 4).
                                 M neighbouring rows are staged as one row and a candidate's accumulator holds the sum of their M
                                 filter sums -- an upper bound of each (non-negative weights), so the filter stays sound; a crossing
-                                becomes M survivors, pruned by the exact scores as ever.  candidate_pairs then counts a candidate
-                                touched by several rows of one round once: a lower bound */
+                                becomes M pairs, each tested against the shard rule on its exact partial score before it is
+                                reported (filter_survivors: no more than without merging).  candidate_pairs then counts a
+                                candidate touched by several rows of one round once: a lower bound */
   int32_t reserved0;
 } apss_stats;
 
