@@ -1595,11 +1595,6 @@ int32_t plan_filter(apss_handle *h, const FilterFacts &f, CxVariant &cxv, ProbeA
     const int64_t row_max = std::min<int64_t>(f.s_max_nnz * M, f.s_nnz_end);  // longest staged row: at most M of the longest
     int flat_group_log2 = 2;
     while (flat_group_log2 > 0 && ceil_div(row_max, kWave >> flat_group_log2) > (int64_t)nw / 4) --flat_group_log2;
-    // (a merged row is long and its terms are short: as FEW staging waves as one lane per term needs, then as many lanes per term as
-    // that number of waves still holds -- T = 8 shard of C3, 60-term merged rows: one staging wave + seven adding waves over a
-    // 3-step window 10.59 ms, two + six over 4 steps 10.96)
-    if (m > 0)
-      while (flat_group_log2 > 0 && ceil_div(row_max, kWave >> flat_group_log2) > ceil_div(row_max, (int64_t)kWave)) --flat_group_log2;
     if (dbg.flat_group >= 0 && dbg.flat_group < flat_group_log2) flat_group_log2 = dbg.flat_group;
     const int64_t flat_waves = std::max<int64_t>(1, ceil_div(row_max, kWave >> flat_group_log2));
     if (!(!cxv.vrows && !cxv.longpf && cxv.chunk == 16 && !dbg.no_even && !dbg.window && flat_waves <= (int64_t)nw / 4 && few_longs)) break;
